@@ -1,0 +1,129 @@
+"""
+Python face of the batch extension (include/pv_koala_batch.h): B lock-stepped streams on one MI355X.
+The reference has no counterpart (one stream per handle, include/pv_koala.h:65-80); stream b of a batch is
+sample-for-sample what its own `Koala` instance would produce.
+"""
+
+import os
+from ctypes import POINTER, byref, c_char_p, c_double, c_int32, c_int64, c_void_p
+from typing import Optional
+
+import numpy as np
+
+from ._koala import (KoalaError, KoalaInvalidArgumentError, KoalaIOError, PicovoiceStatuses, load_library,
+                     raise_status)
+
+PRECISION_FP32 = 0
+PRECISION_BF16 = 1
+KERNEL_CLASSES = ('analysis', 'gemm_input', 'gru_recurrent', 'gemm_head', 'synthesis')
+
+
+class KoalaBatch(object):
+    def __init__(self, access_key: str, model_path: str, device: str, library_path: str, num_streams: int,
+                 max_frames_per_call: int = 1, precision: str = 'fp32') -> None:
+        if not isinstance(access_key, str) or len(access_key) == 0:
+            raise KoalaInvalidArgumentError("`access_key` should be a non-empty string.")
+        if not os.path.exists(model_path):
+            raise KoalaIOError("Could not find model file at `%s`." % model_path)
+        if precision not in ('fp32', 'bf16'):
+            raise KoalaInvalidArgumentError("`precision` should be `fp32` or `bf16`.")
+        lib = load_library(library_path)
+        lib.pv_set_sdk(b'python')
+        self._lib = lib
+        lib.pv_koala_batch_init.argtypes = [c_char_p, c_char_p, c_char_p, c_int32, c_int32, c_int32, POINTER(c_void_p)]
+        lib.pv_koala_batch_init.restype = PicovoiceStatuses
+        for name, args in (('process_chunk', [c_void_p, c_int32, c_void_p, c_void_p]), ('reset', [c_void_p, c_void_p]),
+                           ('set_stream', [c_void_p, c_void_p]), ('synchronize', [c_void_p]),
+                           ('profile_enable', [c_void_p, c_int32]),
+                           ('profile_read', [c_void_p, POINTER(c_double), POINTER(c_int64)]),
+                           ('delay_sample', [c_void_p, POINTER(c_int32)])):
+            fn = getattr(lib, 'pv_koala_batch_' + name)
+            fn.argtypes = args
+            fn.restype = PicovoiceStatuses
+        lib.pv_koala_batch_delete.argtypes = [c_void_p]
+        lib.pv_koala_batch_delete.restype = None
+        lib.pv_koala_batch_debug_read.argtypes = [c_void_p, c_int32, c_void_p, c_int64]
+        lib.pv_koala_batch_debug_read.restype = c_int64
+
+        self._handle = c_void_p()
+        status = lib.pv_koala_batch_init(access_key.encode(), model_path.encode(), device.encode(), num_streams,
+                                         max_frames_per_call, PRECISION_BF16 if precision == 'bf16' else PRECISION_FP32,
+                                         byref(self._handle))
+        if status is not PicovoiceStatuses.SUCCESS:
+            raise_status(lib, status, 'Initialization failed')
+        self.num_streams = num_streams
+        self.max_frames_per_call = max_frames_per_call
+        self.precision = precision
+        self.frame_length = lib.pv_koala_frame_length()
+        self.sample_rate = lib.pv_sample_rate()
+        d = c_int32()
+        self._check(lib.pv_koala_batch_delay_sample(self._handle, byref(d)), 'Failed to get delay samples')
+        self.delay_sample = d.value
+
+    def _check(self, status, what):
+        if status is not PicovoiceStatuses.SUCCESS:
+            raise_status(self._lib, status, what)
+
+    def process(self, pcm: np.ndarray) -> np.ndarray:
+        """pcm: int16 [num_streams, T*256] in host memory -> enhanced, same shape (synchronous)."""
+        a = np.ascontiguousarray(pcm, dtype=np.int16)
+        if a.ndim != 2 or a.shape[0] != self.num_streams or a.shape[1] % self.frame_length:
+            raise KoalaInvalidArgumentError("expected int16 array of shape [%d, T*%d]" % (self.num_streams, self.frame_length))
+        out = np.empty_like(a)
+        self._check(self._lib.pv_koala_batch_process_chunk(self._handle, a.shape[1] // self.frame_length,
+                                                           a.ctypes.data, out.ctypes.data), 'Processing failed')
+        return out
+
+    def process_device(self, num_frames: int, pcm_ptr: int, enhanced_ptr: int) -> None:
+        """Device pointers (e.g. torch_tensor.data_ptr()) of int16 [num_streams, num_frames*256]; asynchronous."""
+        self._check(self._lib.pv_koala_batch_process_chunk(self._handle, num_frames, c_void_p(pcm_ptr),
+                                                           c_void_p(enhanced_ptr)), 'Processing failed')
+
+    def reset(self, stream_mask: Optional[np.ndarray] = None) -> None:
+        ptr = None
+        if stream_mask is not None:
+            m = np.ascontiguousarray(stream_mask, dtype=np.uint8)
+            if m.shape != (self.num_streams,):
+                raise KoalaInvalidArgumentError("`stream_mask` must have one entry per stream")
+            ptr = m.ctypes.data
+        self._check(self._lib.pv_koala_batch_reset(self._handle, ptr), 'Reset failed')
+
+    def set_stream(self, hip_stream: int) -> None:
+        self._check(self._lib.pv_koala_batch_set_stream(self._handle, c_void_p(hip_stream)), 'set_stream failed')
+
+    def synchronize(self) -> None:
+        self._check(self._lib.pv_koala_batch_synchronize(self._handle), 'synchronize failed')
+
+    def profile_enable(self, enable: bool = True) -> None:
+        self._check(self._lib.pv_koala_batch_profile_enable(self._handle, 1 if enable else 0), 'profile failed')
+
+    def profile_read(self):
+        ms = (c_double * 5)()
+        n = (c_int64 * 5)()
+        self._check(self._lib.pv_koala_batch_profile_read(self._handle, ms, n), 'profile failed')
+        return {k: {'ms': ms[i], 'launches': n[i]} for i, k in enumerate(KERNEL_CLASSES)}
+
+    def debug_read(self, what: str, num_frames: int) -> np.ndarray:
+        shapes = {'features': (0, (num_frames, self.num_streams, 257)), 'spectrum': (1, (num_frames, self.num_streams, 257, 2)),
+                  'mask': (2, (num_frames, self.num_streams, 257)), 'hidden': (3, (8, self.num_streams, 271)),
+                  'embed': (4, (num_frames, self.num_streams, 271))}
+        code, shape = shapes[what]
+        out = np.empty(shape, np.float32)
+        n = self._lib.pv_koala_batch_debug_read(self._handle, code, out.ctypes.data, out.size)
+        if n != out.size:
+            raise KoalaError("debug_read(%s) returned %d, expected %d" % (what, n, out.size))
+        return out
+
+    def delete(self) -> None:
+        if self._handle:
+            self._lib.pv_koala_batch_delete(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.delete()
+        except Exception:
+            pass
+
+
+__all__ = ['KoalaBatch', 'PRECISION_FP32', 'PRECISION_BF16', 'KERNEL_CLASSES']

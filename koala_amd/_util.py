@@ -1,0 +1,37 @@
+"""Locations of the native library and the default KNS1 model (mirrors reference binding/python/_util.py:59-84)."""
+
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+
+
+def default_library_path(relative: str = '') -> str:
+    """The in-tree HIP build of libpv_koala.so (gfx950 only)."""
+    return os.path.join(_PKG, relative, 'lib', 'libpv_koala.so')
+
+
+def default_model_path(relative: str = '') -> str:
+    """The default parameter file written by `build_native()` (hand-built spectral-gate set, see params.py)."""
+    return os.path.join(_PKG, relative, 'lib', 'koala_params.kns')
+
+
+def build_native(force: bool = False) -> str:
+    """Compile koala_amd/lib/libpv_koala.so with hipcc for gfx950 (no GPU needed) and write the default model."""
+    lib = default_library_path()
+    src_dir = os.path.join(_PKG, 'csrc')
+    deps = [os.path.join(src_dir, n) for n in os.listdir(src_dir)]
+    deps += [os.path.join(_PKG, 'Makefile')]
+    inc = os.path.join(_PKG, '..', 'include')
+    if os.path.isdir(inc):
+        deps += [os.path.join(inc, n) for n in os.listdir(inc)]
+    if force or not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
+        subprocess.check_call(['make', '-C', _PKG, '-s', 'lib/libpv_koala.so'])
+    model = default_model_path()
+    if not os.path.exists(model):
+        from . import params
+        params.write_params(model, params.make_gate())
+    return lib
+
+
+__all__ = ['default_library_path', 'default_model_path', 'build_native']

@@ -1,0 +1,635 @@
+// kns_engine.cpp -- parameter loading/packing, HBM workspace and the per-chunk kernel sequence of the KNS-v1 engine.
+//
+// Sequence for one call of B streams x T frames (23 launches, independent of T):
+//   analysis -> front-end GEMM -> 4 x { input GEMM A -> recurrent A -> input GEMM B -> recurrent B -> head GEMM } -> synthesis
+// which is the batched form of what one pv_koala_process call does for one stream and one frame
+// (reference include/pv_koala.h:65-80; stage structure per lib/common/koala_params.pv).
+#include "kns_engine.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace kns {
+
+// ------------------------------------------------------------------------------------------------ parameter file
+
+namespace {
+
+bool read_vec(FILE *f, std::vector<float> *v, size_t n) {
+    v->resize(n);
+    return fread(v->data(), sizeof(float), n, f) == n;
+}
+
+}  // namespace
+
+LoadResult load_params(const char *path, Params *p, std::string *err) {
+    FILE *f = fopen(path, "rb");
+    if (!f) {
+        *err = std::string("Failed to open file `") + path + "`.";
+        return kLoadIo;
+    }
+    char magic[8];
+    uint32_t hdr[14];
+    bool ok = fread(magic, 1, 8, f) == 8 && fread(hdr, 4, 14, f) == 14 && memcmp(magic, "KNS1\0\0\0\0", 8) == 0;
+    ok = ok && hdr[0] == 1 && hdr[1] == kNfft && hdr[2] == kFrame && hdr[3] == kBins && hdr[4] == kHidden &&
+         hdr[5] == kStages && hdr[9] == kBins && hdr[10] == kFrame;
+    if (!ok) {
+        fclose(f);
+        *err = std::string("`") + path + "` is not a Koala (KNS1) model file.";
+        return kLoadFormat;
+    }
+    const size_t G3 = 3 * kHidden;
+    ok = read_vec(f, &p->mean, kBins) && read_vec(f, &p->scale, kBins) && read_vec(f, &p->w_in, (size_t) kBins * kHidden) &&
+         read_vec(f, &p->b_in, kHidden);
+    for (int s = 0; ok && s < kStages; ++s) {
+        Params::Stage &st = p->st[s];
+        p->head[s] = (int) hdr[6 + s];
+        st.d_in = s ? p->head[s - 1] : 0;
+        st.d_out = p->head[s];
+        if (st.d_out <= 0 || st.d_out > kBins) {
+            ok = false;
+            break;
+        }
+        ok = read_vec(f, &st.w_ih_a, (size_t) (st.d_in + kHidden) * G3) && read_vec(f, &st.b_ih_a, G3) &&
+             read_vec(f, &st.w_hh_a, (size_t) kHidden * G3) && read_vec(f, &st.b_hh_a, G3) &&
+             read_vec(f, &st.w_ih_b, (size_t) kHidden * G3) && read_vec(f, &st.b_ih_b, G3) &&
+             read_vec(f, &st.w_hh_b, (size_t) kHidden * G3) && read_vec(f, &st.b_hh_b, G3) &&
+             read_vec(f, &st.w_head, (size_t) kHidden * st.d_out) && read_vec(f, &st.b_head, (size_t) st.d_out);
+    }
+    ok = ok && fgetc(f) == EOF;
+    fclose(f);
+    if (!ok) {
+        *err = "Failed to read parameter from file.";
+        return kLoadFormat;
+    }
+    return kLoadOk;
+}
+
+// ------------------------------------------------------------------------------------------------ weight packing
+
+namespace {
+
+struct Seg {
+    int k0, klen;
+};
+struct Tile {
+    int c0, valid;
+};
+
+uint16_t to_bf16(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t) (u >> 16);
+}
+
+std::vector<Tile> dense_tiles(int n, int multiple) {
+    std::vector<Tile> t;
+    for (int c = 0; c < n; c += 16) t.push_back({c, n - c < 16 ? n - c : 16});
+    while (t.size() % (size_t) multiple) t.push_back({0, 0});
+    return t;
+}
+
+std::vector<Tile> gru_tiles() {  // [unit tile][gate]: what one lane needs for a hidden unit sits in adjacent tiles
+    std::vector<Tile> t;
+    for (int u = 0; u < kUnitTiles; ++u)
+        for (int g = 0; g < 3; ++g) {
+            int left = kHidden - u * 16;
+            t.push_back({g * kHidden + u * 16, left < 16 ? left : 16});
+        }
+    return t;
+}
+
+// B-packed image of W[k][n] (row-major, leading dimension ldw): [n-tile][k-block][lane][16 B]
+std::vector<uint8_t> pack_b(const float *W, int ldw, const std::vector<Seg> &segs, const std::vector<Tile> &tiles,
+                            int precision) {
+    const PrecInfo pi = prec_info(precision);
+    int nb = 0;
+    for (const Seg &s : segs) nb += ceil_div(s.klen, pi.kb);
+    std::vector<uint8_t> out(tiles.size() * (size_t) nb * 1024, 0);
+    for (size_t nt = 0; nt < tiles.size(); ++nt) {
+        int blk = 0;
+        for (const Seg &s : segs) {
+            for (int b = 0; b < ceil_div(s.klen, pi.kb); ++b, ++blk) {
+                uint8_t *dst = out.data() + (nt * nb + blk) * 1024;
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < pi.epl; ++e) {
+                        const int kk = precision == kBf16 ? (lane >> 4) * 8 + e : e * 4 + (lane >> 4);
+                        const int k = b * pi.kb + kk, n = lane & 15;
+                        float v = 0.0f;
+                        if (k < s.klen && n < tiles[nt].valid) v = W[(size_t) (s.k0 + k) * ldw + tiles[nt].c0 + n];
+                        if (precision == kBf16) {
+                            uint16_t h = to_bf16(v);
+                            memcpy(dst + (lane * 8 + e) * 2, &h, 2);
+                        } else {
+                            memcpy(dst + (lane * 4 + e) * 4, &v, 4);
+                        }
+                    }
+            }
+        }
+    }
+    return out;
+}
+
+std::vector<float> pack_bias(const float *b, const std::vector<Tile> &tiles) {
+    std::vector<float> out(tiles.size() * 16, 0.0f);
+    for (size_t nt = 0; nt < tiles.size(); ++nt)
+        for (int n = 0; n < tiles[nt].valid; ++n) out[nt * 16 + n] = b[tiles[nt].c0 + n];
+    return out;
+}
+
+}  // namespace
+
+int visible_gpu_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void) hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+std::string gpu_name(int device) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        (void) hipGetLastError();
+        return "unknown";
+    }
+    if (prop.name[0]) return prop.name;
+    return std::string("AMD GPU ") + prop.gcnArchName;  // some ROCm installs leave the marketing name empty
+}
+
+// ------------------------------------------------------------------------------------------------ engine
+
+void *Engine::dalloc(size_t bytes, bool zero) {
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) {
+        (void) hipGetLastError();
+        alloc_failed_ = true;
+        return nullptr;
+    }
+    allocs_.push_back(p);
+    if (zero) (void) hipMemset(p, 0, bytes);
+    return p;
+}
+
+void *Engine::upload(const void *src, size_t bytes) {
+    void *p = dalloc(bytes, false);
+    if (p) (void) hipMemcpy(p, src, bytes, hipMemcpyHostToDevice);
+    return p;
+}
+
+Engine *Engine::create(const Params &p, int device, int num_streams, int max_frames, int precision, std::string *err,
+                       bool *oom) {
+    Engine *e = new Engine();
+    *oom = false;
+    if (!e->init(p, device, num_streams, max_frames, precision, err, oom)) {
+        delete e;
+        return nullptr;
+    }
+    return e;
+}
+
+bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, std::string *err, bool *oom) {
+    if (hipSetDevice(device) != hipSuccess) {
+        (void) hipGetLastError();
+        *err = "Failed to communicate with device.";
+        return false;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        (void) hipGetLastError();
+        *err = "Failed to communicate with device.";
+        return false;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        *err = std::string("GPU `") + prop.gcnArchName + "` is not supported: this build carries gfx950 (MI355X) code only.";
+        return false;
+    }
+    device_ = device;
+    B_ = B;
+    Bpad_ = ceil_div(B, 16) * 16;
+    Tmax_ = Tmax;
+    prec_ = precision;
+    pi_ = prec_info(precision);
+    nbf_ = ceil_div(kBins, pi_.kb);
+    nbh_ = ceil_div(kHidden, pi_.kb);
+    if (hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking) != hipSuccess) {
+        (void) hipGetLastError();
+        *err = "Failed to create a HIP stream.";
+        return false;
+    }
+    stream_ = own_stream_;
+
+    // ---- tables
+    std::vector<float> win(kNfft), tw(2 * kNfft);
+    const double pi = 3.14159265358979323846;
+    for (int n = 0; n < kNfft; ++n) {
+        win[n] = (float) sin(pi * (double) n / kNfft);
+        tw[2 * n] = (float) cos(2.0 * pi * (double) n / kNfft);
+        tw[2 * n + 1] = (float) -sin(2.0 * pi * (double) n / kNfft);
+    }
+    d_window_ = (float *) upload(win.data(), win.size() * 4);
+    d_twiddle_ = (float *) upload(tw.data(), tw.size() * 4);
+    d_mean_ = (float *) upload(p.mean.data(), kBins * 4);
+    d_scale_ = (float *) upload(p.scale.data(), kBins * 4);
+
+    // ---- weights, pre-packed into MFMA B-fragment order
+    const int G3 = 3 * kHidden;
+    {
+        auto tiles = dense_tiles(kHidden, pi_.npb);
+        auto w = pack_b(p.w_in.data(), kHidden, {{0, kBins}}, tiles, precision);
+        auto b = pack_bias(p.b_in.data(), tiles);
+        w_in_ = upload(w.data(), w.size());
+        b_in_ = (float *) upload(b.data(), b.size() * 4);
+    }
+    const auto gt = gru_tiles();
+    for (int s = 0; s < kStages; ++s) {
+        const Params::Stage &st = p.st[s];
+        StageDev &d = sd_[s];
+        std::vector<Seg> segs_a;
+        if (st.d_in) segs_a.push_back({0, st.d_in});
+        segs_a.push_back({st.d_in, kHidden});
+        auto pk = [&](const std::vector<float> &w, const std::vector<Seg> &segs) {
+            auto img = pack_b(w.data(), G3, segs, gt, precision);
+            return upload(img.data(), img.size());
+        };
+        auto pb = [&](const std::vector<float> &b) {
+            auto img = pack_bias(b.data(), gt);
+            return (float *) upload(img.data(), img.size() * 4);
+        };
+        d.w_ih_a = pk(st.w_ih_a, segs_a);
+        d.w_hh_a = pk(st.w_hh_a, {{0, kHidden}});
+        d.w_ih_b = pk(st.w_ih_b, {{0, kHidden}});
+        d.w_hh_b = pk(st.w_hh_b, {{0, kHidden}});
+        d.b_ih_a = pb(st.b_ih_a);
+        d.b_hh_a = pb(st.b_hh_a);
+        d.b_ih_b = pb(st.b_ih_b);
+        d.b_hh_b = pb(st.b_hh_b);
+        auto ht = dense_tiles(st.d_out, s < kStages - 1 ? pi_.npb : 1);
+        auto hw = pack_b(st.w_head.data(), st.d_out, {{0, kHidden}}, ht, precision);
+        auto hb = pack_bias(st.b_head.data(), ht);
+        d.w_head = upload(hw.data(), hw.size());
+        d.b_head = (float *) upload(hb.data(), hb.size() * 4);
+        d.head_tiles = (int) ht.size();
+        d.head_dim = st.d_out;
+        nby_[s] = ceil_div(st.d_out, pi_.kb);
+    }
+
+    // ---- per-stream state
+    const size_t mtb = (size_t) Bpad_ / 16;
+    d_hist_[0] = (int16_t *) dalloc((size_t) Bpad_ * kFrame * 2, true);
+    d_hist_[1] = (int16_t *) dalloc((size_t) Bpad_ * kFrame * 2, true);
+    d_tail_ = (float *) dalloc((size_t) Bpad_ * kFrame * 4, true);
+    d_hstate_ = (float *) dalloc((size_t) kGruLayers * mtb * kUnitTiles * 1024, true);
+    d_rmask_ = (uint8_t *) dalloc((size_t) Bpad_, true);
+
+    // ---- activation workspace
+    const size_t M = mtb * (size_t) Tmax_;  // m-tiles per call
+    d_spec_ = (float *) dalloc((size_t) Tmax_ * Bpad_ * 256 * 8, true);
+    d_feat_ = dalloc(M * nbf_ * 1024, true);
+    d_e_ = dalloc(M * nbh_ * 1024, true);
+    for (int s = 0; s < kStages - 1; ++s) d_y_[s] = dalloc(M * nby_[s] * 1024, true);
+    d_gi_ = dalloc(M * kGateTiles * 64 * pi_.gisz, true);
+    d_hseq_a_ = dalloc(M * nbh_ * 1024, true);
+    d_hseq_b_ = dalloc(M * nbh_ * 1024, true);
+    d_mask_ = (float *) dalloc(M * kMaskTiles * 1024, true);
+    d_in_ = (int16_t *) dalloc((size_t) B_ * Tmax_ * kFrame * 2, true);
+    d_out_ = (int16_t *) dalloc((size_t) B_ * Tmax_ * kFrame * 2, true);
+    if (alloc_failed_) {
+        *oom = true;
+        *err = "Failed to allocate device memory.";
+        return false;
+    }
+    if (hipHostMalloc((void **) &h_in_, (size_t) B_ * Tmax_ * kFrame * 2, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **) &h_out_, (size_t) B_ * Tmax_ * kFrame * 2, hipHostMallocDefault) != hipSuccess) {
+        (void) hipGetLastError();
+        *oom = true;
+        *err = "Failed to allocate pinned host memory.";
+        return false;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) {
+        *err = std::string("Device initialisation failed: ") + hipGetErrorString(hipGetLastError());
+        return false;
+    }
+    return true;
+}
+
+Engine::~Engine() {
+    if (own_stream_) (void) hipStreamSynchronize(own_stream_);
+    for (Span &s : spans_) {
+        (void) hipEventDestroy(s.a);
+        (void) hipEventDestroy(s.b);
+    }
+    for (hipEvent_t e : pool_) (void) hipEventDestroy(e);
+    for (void *p : allocs_) (void) hipFree(p);
+    if (h_in_) (void) hipHostFree(h_in_);
+    if (h_out_) (void) hipHostFree(h_out_);
+    if (own_stream_) (void) hipStreamDestroy(own_stream_);
+}
+
+void Engine::tick(int) {
+    if (!profiling_) return;
+    hipEvent_t e;
+    if (pool_.empty()) {
+        (void) hipEventCreate(&e);
+    } else {
+        e = pool_.back();
+        pool_.pop_back();
+    }
+    (void) hipEventRecord(e, stream_);
+    pending_ = e;
+}
+
+void Engine::tock(int cls) {
+    if (!profiling_) return;
+    hipEvent_t e;
+    if (pool_.empty()) {
+        (void) hipEventCreate(&e);
+    } else {
+        e = pool_.back();
+        pool_.pop_back();
+    }
+    (void) hipEventRecord(e, stream_);
+    spans_.push_back({cls, pending_, e});
+}
+
+void Engine::profile_enable(bool on) {
+    profiling_ = on;
+    if (on) {
+        for (int i = 0; i < kNumKernelClasses; ++i) {
+            acc_ms_[i] = 0;
+            acc_n_[i] = 0;
+        }
+    }
+}
+
+bool Engine::profile_read(double *ms, int64_t *launches, std::string *err) {
+    if (hipStreamSynchronize(stream_) != hipSuccess) {
+        *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
+        return false;
+    }
+    for (Span &s : spans_) {
+        float t = 0;
+        (void) hipEventElapsedTime(&t, s.a, s.b);
+        acc_ms_[s.cls] += t;
+        acc_n_[s.cls] += 1;
+        pool_.push_back(s.a);
+        pool_.push_back(s.b);
+    }
+    spans_.clear();
+    for (int i = 0; i < kNumKernelClasses; ++i) {
+        ms[i] = acc_ms_[i];
+        launches[i] = acc_n_[i];
+    }
+    return true;
+}
+
+bool Engine::synchronize(std::string *err) {
+    if (hipStreamSynchronize(stream_) != hipSuccess) {
+        *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
+        return false;
+    }
+    return true;
+}
+
+bool Engine::reset(const uint8_t *host_mask, std::string *err) {
+    (void) hipSetDevice(device_);
+    ResetArgs r;
+    r.hist = d_hist_[0];
+    r.hist2 = d_hist_[1];
+    r.tail = d_tail_;
+    r.hstate = d_hstate_;
+    r.Bpad = Bpad_;
+    r.mask = nullptr;
+    if (host_mask) {
+        std::vector<uint8_t> m((size_t) Bpad_, 0);
+        memcpy(m.data(), host_mask, (size_t) B_);
+        (void) hipMemcpyAsync(d_rmask_, m.data(), (size_t) Bpad_, hipMemcpyHostToDevice, stream_);
+        (void) hipStreamSynchronize(stream_);  // `m` goes out of scope
+        r.mask = d_rmask_;
+    }
+    launch_reset(r, stream_);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        *err = std::string("HIP error: ") + hipGetErrorString(e);
+        return false;
+    }
+    return true;
+}
+
+bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string *err) {
+    const int mtb = Bpad_ / 16;
+    const int M = mtb * T;
+    last_T_ = T;
+
+    AnalysisArgs an;
+    an.pcm = d_pcm;
+    an.hist_in = d_hist_[hist_cur_];
+    an.hist_out = d_hist_[hist_cur_ ^ 1];
+    an.window = d_window_;
+    an.twiddle = d_twiddle_;
+    an.mean = d_mean_;
+    an.scale = d_scale_;
+    an.spec = d_spec_;
+    an.feat = d_feat_;
+    an.B = B_;
+    an.Bpad = Bpad_;
+    an.T = T;
+    an.nbf = nbf_;
+    an.precision = prec_;
+    tick(kClsAnalysis);
+    launch_analysis(an, stream_);
+    tock(kClsAnalysis);
+    hist_cur_ ^= 1;
+
+    auto gemm = [&](int cls, const void *a0, int nb0, const void *a1, int nb1, const void *w, const float *bias,
+                    void *out, int ntiles, int n_valid, int kind) {
+        GemmArgs g;
+        g.a0 = a0;
+        g.a1 = a1;
+        g.w = w;
+        g.bias = bias;
+        g.out = out;
+        g.nb0 = nb0;
+        g.nb1 = nb1;
+        g.mtiles = M;
+        g.ntiles = ntiles;
+        g.n_valid = n_valid;
+        g.out_kind = kind;
+        g.precision = prec_;
+        tick(cls);
+        launch_gemm(g, stream_);
+        tock(cls);
+    };
+    auto gru = [&](const void *whh, const float *bhh, int layer, void *hseq) {
+        GruArgs g;
+        g.gi = d_gi_;
+        g.whh = whh;
+        g.bhh = bhh;
+        g.hstate = d_hstate_ + (size_t) layer * mtb * kUnitTiles * 256;
+        g.hseq = hseq;
+        g.T = T;
+        g.mtiles = mtb;
+        g.precision = prec_;
+        tick(kClsGru);
+        launch_gru(g, stream_);
+        tock(kClsGru);
+    };
+
+    // front-end: e = features . W_in + b_in
+    gemm(kClsGemmHead, nullptr, 0, d_feat_, nbf_, w_in_, b_in_, d_e_, nbh_ * pi_.npb, kHidden, kOutAPlain);
+    for (int s = 0; s < kStages; ++s) {
+        const StageDev &d = sd_[s];
+        const void *yprev = s ? d_y_[s - 1] : nullptr;
+        const int nby = s ? nby_[s - 1] : 0;
+        gemm(kClsGemmIn, yprev, nby, d_e_, nbh_, d.w_ih_a, d.b_ih_a, d_gi_, kGateTiles, 3 * kHidden, kOutGi);
+        gru(d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_);
+        gemm(kClsGemmIn, nullptr, 0, d_hseq_a_, nbh_, d.w_ih_b, d.b_ih_b, d_gi_, kGateTiles, 3 * kHidden, kOutGi);
+        gru(d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_);
+        if (s < kStages - 1)
+            gemm(kClsGemmHead, nullptr, 0, d_hseq_b_, nbh_, d.w_head, d.b_head, d_y_[s], d.head_tiles, d.head_dim,
+                 kOutASigmoid);
+        else
+            gemm(kClsGemmHead, nullptr, 0, d_hseq_b_, nbh_, d.w_head, d.b_head, d_mask_, d.head_tiles, kBins, kOutMask);
+    }
+
+    SynthesisArgs sy;
+    sy.spec = d_spec_;
+    sy.mask = d_mask_;
+    sy.window = d_window_;
+    sy.twiddle = d_twiddle_;
+    sy.tail = d_tail_;
+    sy.out = d_out;
+    sy.B = B_;
+    sy.Bpad = Bpad_;
+    sy.T = T;
+    tick(kClsSynthesis);
+    launch_synthesis(sy, stream_);
+    tock(kClsSynthesis);
+
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        *err = std::string("HIP launch error: ") + hipGetErrorString(e);
+        return false;
+    }
+    return true;
+}
+
+static bool is_device_pointer(const void *p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void) hipGetLastError();
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err) {
+    (void) hipSetDevice(device_);
+    const size_t bytes = (size_t) B_ * T * kFrame * 2;
+    const bool dev_in = is_device_pointer(pcm), dev_out = is_device_pointer(out);
+    if (dev_in != dev_out) {
+        *err = "`pcm` and `enhanced` must both be host or both be device memory.";
+        return false;
+    }
+    if (dev_in) return run_device(T, pcm, out, err);
+    memcpy(h_in_, pcm, bytes);
+    if (hipMemcpyAsync(d_in_, h_in_, bytes, hipMemcpyHostToDevice, stream_) != hipSuccess) goto fail;
+    if (!run_device(T, d_in_, d_out_, err)) return false;
+    if (hipMemcpyAsync(h_out_, d_out_, bytes, hipMemcpyDeviceToHost, stream_) != hipSuccess) goto fail;
+    if (hipStreamSynchronize(stream_) != hipSuccess) goto fail;
+    memcpy(out, h_out_, bytes);
+    return true;
+fail:
+    *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------------ debug taps
+
+static float bf16_to_float(uint16_t h) {
+    uint32_t u = (uint32_t) h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+int64_t Engine::debug_read(int what, float *out, int64_t capacity, std::string *err) {
+    (void) hipSetDevice(device_);
+    if (hipStreamSynchronize(stream_) != hipSuccess) {
+        *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
+        return -1;
+    }
+    const int T = last_T_, mtb = Bpad_ / 16;
+    auto fetch = [&](const void *d, size_t bytes) {
+        std::vector<uint8_t> h(bytes);
+        (void) hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost);
+        return h;
+    };
+    // logical element (row r of m-tile, k) of an A-packed buffer with nb blocks per m-tile
+    auto a_at = [&](const std::vector<uint8_t> &h, size_t mtile, int nb, int r, int k) -> float {
+        const size_t blk = mtile * nb + k / pi_.kb;
+        const int off = pack_off(prec_, r, k % pi_.kb);
+        if (prec_ == kBf16) {
+            uint16_t v;
+            memcpy(&v, h.data() + blk * 1024 + (size_t) off * 2, 2);
+            return bf16_to_float(v);
+        }
+        float v;
+        memcpy(&v, h.data() + blk * 1024 + (size_t) off * 4, 4);
+        return v;
+    };
+    int64_t n = 0;
+    if (what == 0 || what == 4) {  // features / embedding
+        const int width = what == 0 ? kBins : kHidden, nb = what == 0 ? nbf_ : nbh_;
+        n = (int64_t) T * B_ * width;
+        if (n > capacity) return -2;
+        auto h = fetch(what == 0 ? d_feat_ : d_e_, (size_t) T * mtb * nb * 1024);
+        for (int t = 0; t < T; ++t)
+            for (int b = 0; b < B_; ++b)
+                for (int k = 0; k < width; ++k)
+                    out[((size_t) t * B_ + b) * width + k] = a_at(h, (size_t) t * mtb + b / 16, nb, b % 16, k);
+    } else if (what == 1) {  // spectrum
+        n = (int64_t) T * B_ * kBins * 2;
+        if (n > capacity) return -2;
+        auto h = fetch(d_spec_, (size_t) T * Bpad_ * 256 * 8);
+        const float *s = (const float *) h.data();
+        for (int t = 0; t < T; ++t)
+            for (int b = 0; b < B_; ++b) {
+                const float *src = s + ((size_t) t * Bpad_ + b) * 512;
+                float *dst = out + ((size_t) t * B_ + b) * kBins * 2;
+                memcpy(dst, src, 512 * 4);
+                dst[512] = src[1];  // Nyquist travels in the imaginary slot of bin 0
+                dst[513] = 0.0f;
+                dst[1] = 0.0f;
+            }
+    } else if (what == 2) {  // mask
+        n = (int64_t) T * B_ * kBins;
+        if (n > capacity) return -2;
+        auto h = fetch(d_mask_, (size_t) T * mtb * kMaskTiles * 1024);
+        const float *s = (const float *) h.data();
+        for (int t = 0; t < T; ++t)
+            for (int b = 0; b < B_; ++b)
+                for (int k = 0; k < kBins; ++k)
+                    out[((size_t) t * B_ + b) * kBins + k] =
+                        s[(((size_t) t * mtb + b / 16) * kMaskTiles + k / 16) * 256 + cpack_off(b % 16, k % 16)];
+    } else if (what == 3) {  // hidden state
+        n = (int64_t) kGruLayers * B_ * kHidden;
+        if (n > capacity) return -2;
+        auto h = fetch(d_hstate_, (size_t) kGruLayers * mtb * kUnitTiles * 1024);
+        const float *s = (const float *) h.data();
+        for (int l = 0; l < kGruLayers; ++l)
+            for (int b = 0; b < B_; ++b)
+                for (int k = 0; k < kHidden; ++k)
+                    out[((size_t) l * B_ + b) * kHidden + k] =
+                        s[(((size_t) l * mtb + b / 16) * kUnitTiles + k / 16) * 256 + cpack_off(b % 16, k % 16)];
+    } else {
+        *err = "unknown debug tap";
+        return -1;
+    }
+    return n;
+}
+
+}  // namespace kns

@@ -1,0 +1,109 @@
+// kns_engine.h -- host-side engine behind both the single-stream and the batch C ABI.
+// One Engine = B lock-stepped streams on one GPU: parameter upload (pre-packed for MFMA), per-stream state in HBM,
+// activation workspace in fragment layouts, and the per-chunk kernel sequence.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "kns_kernels.h"
+
+namespace kns {
+
+// host copy of a KNS1 parameter file (fp32, logical layout; see koala_amd/params.py)
+struct Params {
+    int head[kStages];
+    std::vector<float> mean, scale, w_in, b_in;
+    struct Stage {
+        int d_in, d_out;
+        std::vector<float> w_ih_a, b_ih_a, w_hh_a, b_hh_a, w_ih_b, b_ih_b, w_hh_b, b_hh_b, w_head, b_head;
+    } st[kStages];
+};
+
+enum LoadResult { kLoadOk = 0, kLoadIo = 1, kLoadFormat = 2 };
+LoadResult load_params(const char *path, Params *out, std::string *err);
+
+constexpr int kNumKernelClasses = 5;
+enum KernelClass { kClsAnalysis = 0, kClsGemmIn = 1, kClsGru = 2, kClsGemmHead = 3, kClsSynthesis = 4 };
+
+class Engine {
+public:
+    // returns nullptr and fills *err on failure (*oom set when the failure was an allocation)
+    static Engine *create(const Params &p, int device, int num_streams, int max_frames, int precision,
+                          std::string *err, bool *oom);
+    ~Engine();
+
+    int num_streams() const { return B_; }
+    int max_frames() const { return Tmax_; }
+    int device() const { return device_; }
+
+    // pcm/out: [B][T*256]; host or device pointers (both of the same kind).  Host: synchronous.  Device: enqueued.
+    bool process(int T, const int16_t *pcm, int16_t *out, std::string *err);
+    bool reset(const uint8_t *host_mask, std::string *err);
+    void set_stream(hipStream_t s) { stream_ = s ? s : own_stream_; }
+    bool synchronize(std::string *err);
+
+    void profile_enable(bool on);
+    bool profile_read(double *ms, int64_t *launches, std::string *err);
+    int64_t debug_read(int what, float *out, int64_t capacity, std::string *err);
+
+private:
+    Engine() {}
+    bool init(const Params &p, int device, int B, int Tmax, int precision, std::string *err, bool *oom);
+    bool run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string *err);
+    void *dalloc(size_t bytes, bool zero);
+    void *upload(const void *src, size_t bytes);
+    void tick(int cls);
+    void tock(int cls);
+
+    int device_ = 0, B_ = 0, Bpad_ = 0, Tmax_ = 0, prec_ = 0, last_T_ = 0;
+    PrecInfo pi_{};
+    int nbf_ = 0, nbh_ = 0, nby_[kStages] = {0, 0, 0, 0};
+    hipStream_t own_stream_ = nullptr, stream_ = nullptr;
+    bool alloc_failed_ = false;
+    std::vector<void *> allocs_;
+
+    // parameters on device
+    float *d_window_ = nullptr, *d_twiddle_ = nullptr, *d_mean_ = nullptr, *d_scale_ = nullptr;
+    void *w_in_ = nullptr;
+    float *b_in_ = nullptr;
+    struct StageDev {
+        void *w_ih_a, *w_hh_a, *w_ih_b, *w_hh_b, *w_head;
+        float *b_ih_a, *b_hh_a, *b_ih_b, *b_hh_b, *b_head;
+        int head_tiles, head_dim;
+    } sd_[kStages]{};
+
+    // per-stream state
+    int16_t *d_hist_[2] = {nullptr, nullptr};
+    int hist_cur_ = 0;
+    float *d_tail_ = nullptr, *d_hstate_ = nullptr;
+    uint8_t *d_rmask_ = nullptr;
+
+    // activation workspace (fragment layouts)
+    float *d_spec_ = nullptr, *d_mask_ = nullptr;
+    void *d_feat_ = nullptr, *d_e_ = nullptr, *d_y_[kStages - 1] = {nullptr, nullptr, nullptr}, *d_gi_ = nullptr,
+         *d_hseq_a_ = nullptr, *d_hseq_b_ = nullptr;
+
+    // staging for host-pointer calls
+    int16_t *d_in_ = nullptr, *d_out_ = nullptr, *h_in_ = nullptr, *h_out_ = nullptr;
+
+    // profiling
+    bool profiling_ = false;
+    struct Span {
+        int cls;
+        hipEvent_t a, b;
+    };
+    std::vector<Span> spans_;
+    std::vector<hipEvent_t> pool_;
+    hipEvent_t pending_ = nullptr;
+    double acc_ms_[kNumKernelClasses] = {0, 0, 0, 0, 0};
+    int64_t acc_n_[kNumKernelClasses] = {0, 0, 0, 0, 0};
+};
+
+int visible_gpu_count();
+std::string gpu_name(int device);
+
+}  // namespace kns

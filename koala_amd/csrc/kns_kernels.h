@@ -1,0 +1,80 @@
+// kns_kernels.h -- launch interface of the gfx950 kernels (kns_kernels.hip).  Host code only sees PODs.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kns_layout.h"
+
+namespace kns {
+
+// ---- analysis: int16 frames -> spectrum + normalised log-power features (SURVEY 8a rows a2+a3)
+struct AnalysisArgs {
+    const int16_t *pcm;       // [B][T*256] row-major (caller layout)
+    const int16_t *hist_in;   // [Bpad][256] last frame of the previous call
+    int16_t *hist_out;        // [Bpad][256] last frame of this call
+    const float *window;      // [512]
+    const float *twiddle;     // [512][2] exp(-2 pi i k / 512)
+    const float *mean;        // [257]
+    const float *scale;       // [257]
+    float *spec;              // [T][Bpad][256][2] packed half spectrum (slot 0 = {X0.re, X256.re})
+    void *feat;               // A-packed [T*mtiles][nbf] blocks
+    int B, Bpad, T, nbf, precision;
+};
+void launch_analysis(const AnalysisArgs &a, hipStream_t s);
+
+// ---- synthesis: mask x spectrum -> iFFT -> window -> overlap-add -> int16
+struct SynthesisArgs {
+    const float *spec;      // as above
+    const float *mask;      // C-packed fp32 [T*mtiles][17][64][4]
+    const float *window;    // [512]
+    const float *twiddle;   // [512][2]
+    float *tail;            // [Bpad][256] overlap-add state (in/out)
+    int16_t *out;           // [B][T*256]
+    int B, Bpad, T;
+};
+void launch_synthesis(const SynthesisArgs &a, hipStream_t s);
+
+// ---- GEMM over all stream-frames: out = act(A . W + bias), A from up to two A-packed sources
+enum GemmOut {
+    kOutGi = 0,        // C-packed pre-activations (fp32 or fp16), no activation
+    kOutMask = 1,      // C-packed fp32, sigmoid
+    kOutAPlain = 2,    // A-packed operand type, no activation
+    kOutASigmoid = 3,  // A-packed operand type, sigmoid
+};
+struct GemmArgs {
+    const void *a0;   // [mtiles][nb0] blocks (may be null when nb0 == 0)
+    const void *a1;   // [mtiles][nb1] blocks
+    const void *w;    // B-packed [ntiles][nb0 + nb1] blocks
+    const float *bias;  // [ntiles * 16]
+    void *out;
+    int nb0, nb1;
+    int mtiles, ntiles;
+    int n_valid;  // logical output width; columns >= n_valid are written as 0 in A-packed outputs
+    int out_kind, precision;
+};
+void launch_gemm(const GemmArgs &a, hipStream_t s);
+
+// ---- recurrent half of one GRU layer over T frames
+struct GruArgs {
+    const void *gi;     // C-packed [T][mtiles][51] tiles of (x . W_ih + b_ih)
+    const void *whh;    // B-packed [51][nbh] blocks
+    const float *bhh;   // [51 * 16]
+    float *hstate;      // C-packed fp32 [mtiles][17][64][4], in/out
+    void *hseq;         // A-packed [T][mtiles][nbh] blocks, out
+    int T, mtiles, precision;
+};
+void launch_gru(const GruArgs &a, hipStream_t s);
+
+// ---- state reset of selected streams
+struct ResetArgs {
+    int16_t *hist;   // [Bpad][256] (both ping-pong copies are cleared)
+    int16_t *hist2;
+    float *tail;     // [Bpad][256]
+    float *hstate;   // [8][mtiles][17][64][4]
+    const uint8_t *mask;  // [Bpad] device copy, or null for all
+    int Bpad;
+};
+void launch_reset(const ResetArgs &a, hipStream_t s);
+
+}  // namespace kns

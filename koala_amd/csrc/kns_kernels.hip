@@ -1,0 +1,705 @@
+// kns_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the KNS-v1 noise suppressor.
+//
+// Hot path of pv_koala_process (reference include/pv_koala.h:65-80), batched over B independent streams and
+// T frames per call:
+//   analysis_kernel   a2+a3  int16 -> window -> real FFT-512 (radix-4 Stockham, one frame per wavefront, LDS
+//                            exchange) -> log-power features, written in MFMA A-fragment order
+//   gemm_kernel       a4     every input-side / front-end / head GEMM: A tile staged once in LDS in fragment
+//                            order, weights streamed from L2 in B-fragment order, MFMA 16x16x32 bf16 or 16x16x4 f32
+//   gru_kernel        a4     recurrent half of a GRU layer: one workgroup owns 16 streams for all T frames, hidden
+//                            state in registers (fp32) and LDS (operand type), no inter-workgroup traffic
+//   synthesis_kernel  a5     mask x spectrum -> inverse real FFT -> window -> overlap-add -> saturated int16
+//
+// Numerics follow DESIGN.md section 2 exactly (k-ascending fmaf chains, polynomial exp/log built from IEEE ops),
+// compiled with -ffp-contract=off so that no operation is fused or split behind the spec's back.
+#include "kns_kernels.h"
+
+namespace kns {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------ scalar math
+
+__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+__device__ __forceinline__ uint16_t f2bf(float x) {  // round to nearest even
+    uint32_t u = f2u(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t) (u >> 16);
+}
+
+__device__ __forceinline__ float kns_exp(float x) {
+    x = __builtin_fminf(__builtin_fmaxf(x, -87.0f), 88.0f);
+    float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float z = r * r;
+    float y = __builtin_fmaf(p, z, r) + 1.0f;
+    int ni = (int) n;
+    return y * u2f((uint32_t) (ni + 127) << 23);
+}
+
+__device__ __forceinline__ float kns_log(float x) {
+    uint32_t u = f2u(x);
+    int e = (int) ((u >> 23) & 0xffu) - 126;
+    float m = u2f((u & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.707106781186547524f) {
+        e -= 1;
+        m = (m + m) - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    float z = m * m;
+    float p = 7.0376836292e-2f;
+    p = __builtin_fmaf(p, m, -1.1514610310e-1f);
+    p = __builtin_fmaf(p, m, 1.1676998740e-1f);
+    p = __builtin_fmaf(p, m, -1.2420140846e-1f);
+    p = __builtin_fmaf(p, m, 1.4249322787e-1f);
+    p = __builtin_fmaf(p, m, -1.6668057665e-1f);
+    p = __builtin_fmaf(p, m, 2.0000714765e-1f);
+    p = __builtin_fmaf(p, m, -2.4999993993e-1f);
+    p = __builtin_fmaf(p, m, 3.3333331174e-1f);
+    float fe = (float) e;
+    float y = (p * m) * z;
+    y = __builtin_fmaf(fe, -2.12194440e-4f, y);
+    y = __builtin_fmaf(z, -0.5f, y);
+    float r = m + y;
+    return __builtin_fmaf(fe, 0.693359375f, r);
+}
+
+__device__ __forceinline__ float kns_sigmoid(float x) { return 1.0f / (1.0f + kns_exp(-x)); }
+
+__device__ __forceinline__ float kns_tanh(float x) {
+    float a = __builtin_fabsf(x);
+    float t = kns_exp(-2.0f * a);
+    float v = (1.0f - t) / (1.0f + t);
+    return __builtin_copysignf(v, x);
+}
+
+// LDS traffic between the lanes of ONE wavefront: DS operations of a wave execute in program order, so only the
+// compiler has to be kept from reordering across this point.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------------------ precision traits
+
+struct PF32 {
+    static constexpr int kPrec = kFp32;
+    static constexpr int KB = 16, EPL = 4, NPB = 1;
+    static constexpr int NBH = 17;  // k-blocks covering the 271 hidden units
+    static constexpr bool kHoldA = false;  // 17 x 4 registers of A fragments would spill: re-read them from LDS
+    static constexpr int kGruWaves = 1;
+    typedef f32x4 frag_t;
+    typedef f32x4 gi_t;
+    typedef float elem_t;
+    static __device__ __forceinline__ f32x4 mma(frag_t a, frag_t b, f32x4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+        return c;
+    }
+    static __device__ __forceinline__ int off(int rc, int kk) { return pack_off_f32(rc, kk); }
+    static __device__ __forceinline__ elem_t cvt(float v) { return v; }
+    static __device__ __forceinline__ gi_t to_gi(f32x4 v) { return v; }
+    static __device__ __forceinline__ f32x4 from_gi(gi_t v) { return v; }
+};
+
+struct PBF16 {
+    static constexpr int kPrec = kBf16;
+    static constexpr int KB = 32, EPL = 8, NPB = 2;
+    static constexpr int NBH = 9;
+    static constexpr bool kHoldA = true;
+    static constexpr int kGruWaves = 1;
+    typedef bf16x8 frag_t;
+    typedef f16x4 gi_t;
+    typedef uint16_t elem_t;
+    static __device__ __forceinline__ f32x4 mma(frag_t a, frag_t b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int off(int rc, int kk) { return pack_off_bf16(rc, kk); }
+    static __device__ __forceinline__ elem_t cvt(float v) { return f2bf(v); }
+    static __device__ __forceinline__ gi_t to_gi(f32x4 v) {
+        gi_t r;
+        r[0] = (_Float16) v[0];
+        r[1] = (_Float16) v[1];
+        r[2] = (_Float16) v[2];
+        r[3] = (_Float16) v[3];
+        return r;
+    }
+    static __device__ __forceinline__ f32x4 from_gi(gi_t v) {
+        f32x4 r;
+        r[0] = (float) v[0];
+        r[1] = (float) v[1];
+        r[2] = (float) v[2];
+        r[3] = (float) v[3];
+        return r;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ FFT-256 per wave
+
+struct cpx {
+    float x, y;
+};
+__device__ __forceinline__ cpx cadd(cpx a, cpx b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cpx csub(cpx a, cpx b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cpx cmul(cpx a, cpx w) {
+    return {__builtin_fmaf(a.x, w.x, -(a.y * w.y)), __builtin_fmaf(a.x, w.y, a.y * w.x)};
+}
+
+__device__ __forceinline__ void radix4(cpx (&v)[4]) {
+    cpx a0 = cadd(v[0], v[2]), a1 = csub(v[0], v[2]), a2 = cadd(v[1], v[3]), d = csub(v[1], v[3]);
+    cpx a3 = {d.y, -d.x};  // (v1 - v3) * (-i)
+    v[0] = cadd(a0, a2);
+    v[1] = cadd(a1, a3);
+    v[2] = csub(a0, a2);
+    v[3] = csub(a1, a3);
+}
+
+// Forward 256-point complex FFT of one wavefront, radix-4 Stockham autosort.  On entry v[r] = z[lane + 64 r].
+// `buf` is this wave's LDS scratch: two ping-pong buffers of {re[256], im[256]}.  On return the spectrum is in
+// natural order in buf[0..511] (re at [k], im at [256 + k]) and visible to the whole wave.
+// tw = exp(-2 pi i k / 512), k = 0..511, in LDS.
+__device__ __forceinline__ void fft256_wave(cpx (&v)[4], float *buf, const float2 *tw, int lane) {
+    float *b0 = buf, *b1 = buf + 512;
+    // stage Ns = 1 (all twiddles are 1)
+    radix4(v);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        b1[4 * lane + r] = v[r].x;
+        b1[256 + 4 * lane + r] = v[r].y;
+    }
+    wave_lds_sync();
+    // stages Ns = 4, 16, 64
+#pragma unroll
+    for (int s = 1; s < 4; ++s) {
+        const int Ns = 1 << (2 * s);
+        float *src = (s & 1) ? b1 : b0;
+        float *dst = (s & 1) ? b0 : b1;
+        const int k = lane & (Ns - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r].x = src[lane + 64 * r];
+            v[r].y = src[256 + lane + 64 * r];
+        }
+#pragma unroll
+        for (int r = 1; r < 4; ++r) {
+            float2 w = tw[r * k * (128 / Ns)];
+            v[r] = cmul(v[r], cpx{w.x, w.y});
+        }
+        radix4(v);
+        const int j0 = (lane / Ns) * Ns * 4 + k;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dst[j0 + r * Ns] = v[r].x;
+            dst[256 + j0 + r * Ns] = v[r].y;
+        }
+        wave_lds_sync();
+    }
+    // s = 1 -> b0, s = 2 -> b1, s = 3 -> b0: result is in b0
+}
+
+// ------------------------------------------------------------------------------------------------ analysis
+
+template <class P>
+__global__ __launch_bounds__(256) void analysis_kernel(AnalysisArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *tw = (float2 *) smem;                         // 4 KiB
+    float *win = (float *) (smem + 4096);                 // 2 KiB
+    float *fftbuf = (float *) (smem + 6144);              // 4 waves x 4 KiB
+    typename P::elem_t *tile = (typename P::elem_t *) (smem + 6144 + 16384);  // nbf KiB, A-packed feature tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mt = blockIdx.x, t = blockIdx.y;
+    const int mtiles = g.Bpad >> 4;
+
+    for (int i = tid; i < 512; i += 256) {
+        tw[i] = ((const float2 *) g.twiddle)[i];
+        win[i] = g.window[i];
+    }
+    {
+        uint4 *z = (uint4 *) tile;
+        for (int i = tid; i < g.nbf * 64; i += 256) z[i] = uint4{0, 0, 0, 0};
+    }
+    __syncthreads();
+
+    float *buf = fftbuf + wave * 1024;
+    const size_t row_len = (size_t) g.T * kFrame;
+
+    for (int f = 0; f < 4; ++f) {
+        const int row = wave * 4 + f;
+        const int b = mt * 16 + row;
+        const bool valid = b < g.B;
+        // lane handles z[n] = x[2n] + i x[2n+1], n = lane + 64 r; r = 0,1 -> history, r = 2,3 -> new frame
+        const int16_t *cur = g.pcm + (size_t) b * row_len + (size_t) t * kFrame;
+        const int16_t *old = (t == 0) ? g.hist_in + (size_t) b * kFrame : cur - kFrame;
+        cpx v[4];
+        int raw[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = lane + 64 * r;
+            const int16_t *src = (r < 2) ? old + 2 * n : cur + 2 * (n - 128);
+            int pr = 0;
+            if (valid) pr = *(const int *) src;
+            raw[r] = pr;
+            float lo = (float) (int16_t) (pr & 0xffff), hi = (float) (int16_t) (pr >> 16);
+            v[r].x = (lo * (1.0f / 32768.0f)) * win[2 * n];
+            v[r].y = (hi * (1.0f / 32768.0f)) * win[2 * n + 1];
+        }
+        if (t == g.T - 1 && b < g.Bpad) {
+            int *h = (int *) (g.hist_out + (size_t) b * kFrame);
+            h[lane] = raw[2];
+            h[lane + 64] = raw[3];
+        }
+        fft256_wave(v, buf, tw, lane);
+        float2 *spec = (float2 *) g.spec + ((size_t) t * g.Bpad + b) * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = lane + 64 * r;
+            const int kc = (256 - k) & 255;
+            cpx zk = {buf[k], buf[256 + k]};
+            cpx zc = {buf[kc], -buf[256 + kc]};
+            float2 w = tw[k];
+            cpx s = cadd(zk, zc), d = csub(zk, zc);
+            cpx p = cmul(d, cpx{w.x, w.y});
+            float xr = 0.5f * (s.x + p.y);
+            float xi = 0.5f * (s.y - p.x);
+            float pw = __builtin_fmaf(xr, xr, xi * xi);
+            float nyq = 0.0f;
+            if (k == 0) {  // DC and Nyquist share packed slot 0
+                xr = zk.x + zk.y;
+                nyq = zk.x - zk.y;
+                xi = nyq;
+                pw = xr * xr;
+            }
+            spec[k] = float2{xr, xi};
+            float ft = (kns_log(pw + 1e-10f) - g.mean[k]) * g.scale[k];
+            tile[(k / P::KB) * 64 * P::EPL + P::off(row, k % P::KB)] = P::cvt(ft);
+            if (k == 0) {
+                float fn = (kns_log(nyq * nyq + 1e-10f) - g.mean[256]) * g.scale[256];
+                tile[(256 / P::KB) * 64 * P::EPL + P::off(row, 256 % P::KB)] = P::cvt(fn);
+            }
+        }
+        wave_lds_sync();
+    }
+    __syncthreads();
+    {
+        const uint4 *src = (const uint4 *) tile;
+        uint4 *dst = (uint4 *) g.feat + ((size_t) t * mtiles + mt) * g.nbf * 64;
+        for (int i = tid; i < g.nbf * 64; i += 256) dst[i] = src[i];
+    }
+}
+
+void launch_analysis(const AnalysisArgs &a, hipStream_t s) {
+    dim3 grid(a.Bpad / 16, a.T);
+    size_t lds = 6144 + 16384 + (size_t) a.nbf * 1024;
+    if (a.precision == kBf16)
+        hipLaunchKernelGGL(analysis_kernel<PBF16>, grid, dim3(256), lds, s, a);
+    else
+        hipLaunchKernelGGL(analysis_kernel<PF32>, grid, dim3(256), lds, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------ synthesis
+
+__global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *tw = (float2 *) smem;
+    float *win = (float *) (smem + 4096);
+    float *fftbuf = (float *) (smem + 6144);
+    float *mtile = (float *) (smem + 6144 + 16384);  // C-packed [17][64][4] fp32
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mt = blockIdx.x;
+    const int mtiles = g.Bpad >> 4;
+    for (int i = tid; i < 512; i += 256) {
+        tw[i] = ((const float2 *) g.twiddle)[i];
+        win[i] = g.window[i];
+    }
+    float *buf = fftbuf + wave * 1024;
+    const size_t row_len = (size_t) g.T * kFrame;
+
+    // overlap-add tail of this wave's four streams: lane holds samples 2n, 2n+1 for n = lane, lane + 64
+    float2 tl[4][2];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int b = mt * 16 + wave * 4 + f;
+        const float2 *tp = (const float2 *) (g.tail + (size_t) b * kFrame);
+        tl[f][0] = tp[lane];
+        tl[f][1] = tp[lane + 64];
+    }
+
+    for (int t = 0; t < g.T; ++t) {
+        __syncthreads();  // previous frame's readers are done with mtile
+        {
+            const uint4 *src = (const uint4 *) g.mask + ((size_t) t * mtiles + mt) * kMaskTiles * 64;
+            uint4 *dst = (uint4 *) mtile;
+            for (int i = tid; i < kMaskTiles * 64; i += 256) dst[i] = src[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int row = wave * 4 + f;
+            const int b = mt * 16 + row;
+            const float2 *spec = (const float2 *) g.spec + ((size_t) t * g.Bpad + b) * 256;
+            cpx v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = lane + 64 * r;
+                const int kc = (256 - k) & 255;
+                float2 xk = spec[k], xc = spec[kc];
+                float mk = mtile[(k >> 4) * 256 + cpack_off(row, k & 15)];
+                const int kcm = 256 - k;  // mask index of the mirrored bin (256 when k == 0)
+                float mc = mtile[(kcm >> 4) * 256 + cpack_off(row, kcm & 15)];
+                cpx yk, yc;
+                if (k == 0) {
+                    yk = {mk * xk.x, 0.0f};
+                    yc = {mc * xk.y, 0.0f};
+                } else {
+                    yk = {mk * xk.x, mk * xk.y};
+                    yc = {mc * xc.x, -(mc * xc.y)};
+                }
+                float2 w = tw[k];
+                cpx e = cadd(yk, yc), d = csub(yk, yc);
+                cpx o = cmul(d, cpx{w.x, -w.y});  // conj(W^k) (yk - yc)
+                // Z' = E + i O (both carry the factor 1/2); fed to the forward FFT with re/im swapped = inverse FFT
+                float zr = 0.5f * (e.x - o.y), zi = 0.5f * (e.y + o.x);
+                v[r] = {zi, zr};
+            }
+            fft256_wave(v, buf, tw, lane);
+            int packed[2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = lane + 64 * r;
+                // swapped output: re <-> im
+                float x0 = buf[256 + n] * (1.0f / 256.0f);
+                float x1 = buf[n] * (1.0f / 256.0f);
+                float y0 = x0 * win[2 * n], y1 = x1 * win[2 * n + 1];
+                if (r < 2) {
+                    float a0 = (tl[f][r].x + y0) * 32768.0f, a1 = (tl[f][r].y + y1) * 32768.0f;
+                    a0 = __builtin_fminf(__builtin_fmaxf(__builtin_roundf(a0), -32768.0f), 32767.0f);
+                    a1 = __builtin_fminf(__builtin_fmaxf(__builtin_roundf(a1), -32768.0f), 32767.0f);
+                    packed[r] = ((int) a0 & 0xffff) | ((int) a1 << 16);
+                } else {
+                    tl[f][r - 2] = float2{y0, y1};
+                }
+            }
+            if (b < g.B) {
+                int *o = (int *) (g.out + (size_t) b * row_len + (size_t) t * kFrame);
+                o[lane] = packed[0];
+                o[lane + 64] = packed[1];
+            }
+            wave_lds_sync();
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int b = mt * 16 + wave * 4 + f;
+        float2 *tp = (float2 *) (g.tail + (size_t) b * kFrame);
+        tp[lane] = tl[f][0];
+        tp[lane + 64] = tl[f][1];
+    }
+}
+
+void launch_synthesis(const SynthesisArgs &a, hipStream_t s) {
+    size_t lds = 6144 + 16384 + kMaskTiles * 1024;
+    hipLaunchKernelGGL(synthesis_kernel, dim3(a.Bpad / 16), dim3(256), lds, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------ GEMM
+
+constexpr int kGemmMT = 4;  // m-tiles (of 16 stream-frames) per workgroup
+constexpr int kPF = 4;      // weight prefetch depth in k-blocks
+
+template <class P, int OUT>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename P::frag_t frag_t;
+    constexpr bool kApack = (OUT == kOutAPlain || OUT == kOutASigmoid);
+    constexpr bool kSigmoid = (OUT == kOutMask || OUT == kOutASigmoid);
+    constexpr int NU = kApack ? P::NPB : 1;  // n-tiles per unit of work
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = g.nb0 + g.nb1;
+    const int mt0 = blockIdx.x * kGemmMT;
+    const int mcount = min(kGemmMT, g.mtiles - mt0);
+
+    // stage the A tile in LDS, keeping fragment order: [m-tile][k-block][lane] 16-byte words
+    uint4 *lds_a = (uint4 *) smem;
+    for (int m = 0; m < mcount; ++m) {
+        if (g.nb0) {
+            const uint4 *src = (const uint4 *) g.a0 + (size_t) (mt0 + m) * g.nb0 * 64;
+            for (int i = tid; i < g.nb0 * 64; i += 256) lds_a[m * nb * 64 + i] = src[i];
+        }
+        const uint4 *src1 = (const uint4 *) g.a1 + (size_t) (mt0 + m) * g.nb1 * 64;
+        for (int i = tid; i < g.nb1 * 64; i += 256) lds_a[(m * nb + g.nb0) * 64 + i] = src1[i];
+    }
+    for (int m = mcount; m < kGemmMT; ++m)
+        for (int i = tid; i < nb * 64; i += 256) lds_a[m * nb * 64 + i] = uint4{0, 0, 0, 0};
+    __syncthreads();
+
+    const frag_t *lds_f = (const frag_t *) smem;
+    char *scratch = smem + (size_t) kGemmMT * nb * 1024 + (size_t) wave * kGemmMT * 1024;  // per-wave transposer
+
+    const int units = g.ntiles / NU;
+    const int units_per_y = ceil_div(units, (int) gridDim.y);
+    const int u_begin = blockIdx.y * units_per_y;
+    const int u_end = min(units, u_begin + units_per_y);
+    const frag_t *w = (const frag_t *) g.w;
+
+    for (int u = u_begin + wave; u < u_end; u += 4) {
+        const int nt0 = u * NU;
+        f32x4 acc[NU][kGemmMT];
+#pragma unroll
+        for (int j = 0; j < NU; ++j)
+#pragma unroll
+            for (int m = 0; m < kGemmMT; ++m) acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        frag_t bq[kPF][NU];
+#pragma unroll
+        for (int p = 0; p < kPF; ++p)
+            if (p < nb)
+#pragma unroll
+                for (int j = 0; j < NU; ++j) bq[p][j] = w[((size_t) (nt0 + j) * nb + p) * 64 + lane];
+        for (int blk0 = 0; blk0 < nb; blk0 += kPF) {
+#pragma unroll
+            for (int p = 0; p < kPF; ++p) {
+                const int blk = blk0 + p;
+                if (blk < nb) {
+                    frag_t bc[NU];
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) bc[j] = bq[p][j];
+                    if (blk + kPF < nb)
+#pragma unroll
+                        for (int j = 0; j < NU; ++j) bq[p][j] = w[((size_t) (nt0 + j) * nb + blk + kPF) * 64 + lane];
+#pragma unroll
+                    for (int m = 0; m < kGemmMT; ++m) {
+                        frag_t a = lds_f[(m * nb + blk) * 64 + lane];
+#pragma unroll
+                        for (int j = 0; j < NU; ++j) acc[j][m] = P::mma(a, bc[j], acc[j][m]);
+                    }
+                }
+            }
+        }
+
+        // epilogue: lane owns column (lane & 15) of each n-tile, rows (lane >> 4) * 4 + i
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            const int nt = nt0 + j;
+            const int col = nt * 16 + (lane & 15);
+            const float bias = g.bias[col];
+#pragma unroll
+            for (int m = 0; m < kGemmMT; ++m) {
+                f32x4 v = acc[j][m];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float x = v[i] + bias;
+                    if (kSigmoid) x = kns_sigmoid(x);
+                    if (kApack && col >= g.n_valid) x = 0.0f;
+                    v[i] = x;
+                }
+                if (!kApack) {
+                    if (m < mcount) {
+                        const size_t idx = ((size_t) (mt0 + m) * g.ntiles + nt) * 64 + lane;
+                        if (OUT == kOutGi)
+                            ((typename P::gi_t *) g.out)[idx] = P::to_gi(v);
+                        else
+                            ((f32x4 *) g.out)[idx] = v;
+                    }
+                } else {
+                    typename P::elem_t *sc = (typename P::elem_t *) (scratch + m * 1024);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sc[P::off((lane >> 4) * 4 + i, j * 16 + (lane & 15))] = P::cvt(v[i]);
+                }
+            }
+        }
+        if (kApack) {
+            wave_lds_sync();
+            const int out_nb = g.ntiles / NU;
+            for (int m = 0; m < mcount; ++m) {
+                uint4 word = ((const uint4 *) (scratch + m * 1024))[lane];
+                ((uint4 *) g.out)[((size_t) (mt0 + m) * out_nb + u) * 64 + lane] = word;
+            }
+            wave_lds_sync();
+        }
+    }
+}
+
+template <class P>
+static void launch_gemm_p(const GemmArgs &a, hipStream_t s) {
+    const int nb = a.nb0 + a.nb1;
+    const int gx = ceil_div(a.mtiles, kGemmMT);
+    const bool apack = a.out_kind == kOutAPlain || a.out_kind == kOutASigmoid;
+    const int units = a.ntiles / (apack ? P::NPB : 1);
+    // few stream-frames: split the n-tiles over more workgroups so the weight stream is spread over the CUs
+    int gy = 1;
+    if (gx < 256) gy = min(ceil_div(units, 4), max(1, 512 / gx));
+    size_t lds = (size_t) kGemmMT * nb * 1024 + 4 * kGemmMT * 1024;
+    dim3 grid(gx, gy);
+    switch (a.out_kind) {
+        case kOutGi: hipLaunchKernelGGL((gemm_kernel<P, kOutGi>), grid, dim3(256), lds, s, a); break;
+        case kOutMask: hipLaunchKernelGGL((gemm_kernel<P, kOutMask>), grid, dim3(256), lds, s, a); break;
+        case kOutAPlain: hipLaunchKernelGGL((gemm_kernel<P, kOutAPlain>), grid, dim3(256), lds, s, a); break;
+        default: hipLaunchKernelGGL((gemm_kernel<P, kOutASigmoid>), grid, dim3(256), lds, s, a); break;
+    }
+}
+
+void launch_gemm(const GemmArgs &a, hipStream_t s) {
+    if (a.precision == kBf16)
+        launch_gemm_p<PBF16>(a, s);
+    else
+        launch_gemm_p<PF32>(a, s);
+}
+
+// ------------------------------------------------------------------------------------------------ recurrent GRU
+
+constexpr int kGruTilesPerWave = 5;  // 17 unit tiles over 4 waves: 5,4,4,4
+
+template <class P>
+__global__ __launch_bounds__(256, P::kGruWaves) void gru_kernel(GruArgs g) {
+    typedef typename P::frag_t frag_t;
+    typedef typename P::elem_t elem_t;
+    constexpr int NBH = P::NBH;
+    __shared__ __attribute__((aligned(16))) char hbuf[2][NBH * 1024];  // operand-typed hidden state, A-packed
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mt = blockIdx.x;
+    const int colq = lane & 15, rowq = (lane >> 4) * 4;
+
+    // fp32 hidden state of the (row, unit) elements this lane owns
+    f32x4 hreg[kGruTilesPerWave];
+#pragma unroll
+    for (int q = 0; q < kGruTilesPerWave; ++q) {
+        const int u = wave + 4 * q;
+        hreg[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (u < kUnitTiles) hreg[q] = ((const f32x4 *) g.hstate)[((size_t) mt * kUnitTiles + u) * 64 + lane];
+    }
+    for (int i = tid; i < 2 * NBH * 64; i += 256) ((uint4 *) hbuf)[i] = uint4{0, 0, 0, 0};
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kGruTilesPerWave; ++q) {
+        const int u = wave + 4 * q;
+        if (u < kUnitTiles) {
+            const int k = u * 16 + colq;
+            elem_t *dst = (elem_t *) hbuf[0] + (k / P::KB) * 64 * P::EPL;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[P::off(rowq + i, k % P::KB)] = P::cvt(hreg[q][i]);
+        }
+    }
+    __syncthreads();
+
+    const frag_t *whh = (const frag_t *) g.whh;
+    int cur = 0;
+    for (int t = 0; t < g.T; ++t) {
+        const frag_t *ha = (const frag_t *) hbuf[cur];
+        frag_t a[P::kHoldA ? NBH : 1];
+        if constexpr (P::kHoldA) {
+#pragma unroll
+            for (int blk = 0; blk < NBH; ++blk) a[blk] = ha[blk * 64 + lane];
+        }
+        if (t > 0) {  // what is in LDS now is h_{t-1}: publish it as the next layer's A operand
+            frag_t *hs = (frag_t *) g.hseq + ((size_t) (t - 1) * g.mtiles + mt) * NBH * 64;
+            for (int blk = wave; blk < NBH; blk += 4) hs[blk * 64 + lane] = ha[blk * 64 + lane];
+        }
+        const typename P::gi_t *gi = (const typename P::gi_t *) g.gi + ((size_t) t * g.mtiles + mt) * kGateTiles * 64;
+#pragma unroll
+        for (int q = 0; q < kGruTilesPerWave; ++q) {
+            const int u = wave + 4 * q;
+            if (u < kUnitTiles) {
+                typename P::gi_t gir = gi[(u * 3 + 0) * 64 + lane];
+                typename P::gi_t giz = gi[(u * 3 + 1) * 64 + lane];
+                typename P::gi_t gin = gi[(u * 3 + 2) * 64 + lane];
+                f32x4 acc[3];
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (P::kHoldA) {
+#pragma unroll
+                    for (int blk = 0; blk < NBH; ++blk) {
+#pragma unroll
+                        for (int gt = 0; gt < 3; ++gt) {
+                            frag_t b = whh[((size_t) (u * 3 + gt) * NBH + blk) * 64 + lane];
+                            acc[gt] = P::mma(a[blk], b, acc[gt]);
+                        }
+                    }
+                } else {
+#pragma nounroll
+                    for (int blk = 0; blk < NBH; ++blk) {
+                        const frag_t ab = ha[blk * 64 + lane];
+#pragma unroll
+                        for (int gt = 0; gt < 3; ++gt) {
+                            frag_t b = whh[((size_t) (u * 3 + gt) * NBH + blk) * 64 + lane];
+                            acc[gt] = P::mma(ab, b, acc[gt]);
+                        }
+                    }
+                }
+                const float br = g.bhh[(u * 3 + 0) * 16 + colq];
+                const float bz = g.bhh[(u * 3 + 1) * 16 + colq];
+                const float bn = g.bhh[(u * 3 + 2) * 16 + colq];
+                f32x4 ir = P::from_gi(gir), iz = P::from_gi(giz), in = P::from_gi(gin);
+                const int k = u * 16 + colq;
+                elem_t *dst = (elem_t *) hbuf[cur ^ 1] + (k / P::KB) * 64 * P::EPL;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float r = kns_sigmoid(ir[i] + (acc[0][i] + br));
+                    float z = kns_sigmoid(iz[i] + (acc[1][i] + bz));
+                    float n = kns_tanh(__builtin_fmaf(r, acc[2][i] + bn, in[i]));
+                    float h = __builtin_fmaf(z, hreg[q][i] - n, n);
+                    hreg[q][i] = h;
+                    dst[P::off(rowq + i, k % P::KB)] = P::cvt(h);
+                }
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    {
+        frag_t *hs = (frag_t *) g.hseq + ((size_t) (g.T - 1) * g.mtiles + mt) * NBH * 64;
+        for (int blk = wave; blk < NBH; blk += 4) hs[blk * 64 + lane] = ((const frag_t *) hbuf[cur])[blk * 64 + lane];
+    }
+#pragma unroll
+    for (int q = 0; q < kGruTilesPerWave; ++q) {
+        const int u = wave + 4 * q;
+        if (u < kUnitTiles) ((f32x4 *) g.hstate)[((size_t) mt * kUnitTiles + u) * 64 + lane] = hreg[q];
+    }
+}
+
+void launch_gru(const GruArgs &a, hipStream_t s) {
+    if (a.precision == kBf16)
+        hipLaunchKernelGGL(gru_kernel<PBF16>, dim3(a.mtiles), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(gru_kernel<PF32>, dim3(a.mtiles), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------ reset
+
+__global__ void reset_kernel(ResetArgs g) {
+    // one workgroup per stream: history, overlap-add tail, and this stream's row of the 8 hidden-state tiles
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (g.mask && !g.mask[b]) return;
+    g.hist[(size_t) b * kFrame + tid] = 0;
+    g.hist2[(size_t) b * kFrame + tid] = 0;
+    g.tail[(size_t) b * kFrame + tid] = 0.0f;
+    const int mtiles = g.Bpad >> 4, mt = b >> 4, row = b & 15;
+    for (int i = tid; i < kGruLayers * kUnitTiles * 16; i += 256) {
+        const int col = i & 15, u = (i >> 4) % kUnitTiles, layer = (i >> 4) / kUnitTiles;
+        g.hstate[(((size_t) layer * mtiles + mt) * kUnitTiles + u) * 256 + cpack_off(row, col)] = 0.0f;
+    }
+}
+
+void launch_reset(const ResetArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(reset_kernel, dim3(a.Bpad), dim3(256), 0, s, a);
+}
+
+}  // namespace kns
