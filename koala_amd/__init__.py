@@ -7,3 +7,4 @@ from ._batch import *
 from ._factory import *
 from ._koala import *
 from ._util import *
+from .sharding import *

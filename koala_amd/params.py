@@ -95,47 +95,98 @@ def make_random(seed: int = 1234, gain: float = 1.0) -> Dict[str, np.ndarray]:
     return t
 
 
-def make_gate(noise_log_power: Optional[np.ndarray] = None) -> Dict[str, np.ndarray]:
-    """
-    Hand-built "spectral gate" parameter set inside the KNS-v1 topology (no training data exists here).
+def noise_prior() -> np.ndarray:
+    """Mean log-power per bin of the reference's noise fixture (tools/make_noise_prior.py)."""
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "noise_prior.npy"))
 
-    features f_k = (log P_k - mean_k) * scale_k are centred on a per-bin threshold (mean_k).  The front-end copies
-    bins 0..256 into the first 257 of the 271 embedding units; every GRU layer is configured as a leaky integrator
-    of its input (update gate held at a constant by its bias, reset gate open, candidate = tanh(unit-wise copy));
-    stage 4's head reads unit k back out as mask_k = sigmoid(gain * h_k).  Heads 1-3 are left at zero weight
-    (constant 0.5 outputs, whose feed-forward weights are zero).
+
+def make_gate(threshold: Optional[np.ndarray] = None, margin: float = 2.15, g1: float = 0.8, z_a: float = 0.2,
+              g2: float = 1.2, z_b: float = 1e-4, g3: float = 10.0, smooth: int = 1, gv: float = 0.8, zv: float = 0.8,
+              kappa: float = 4.0, theta: float = -0.45, zvb: float = 0.6, a: float = 4.0, beta: float = 0.4,
+              width: float = 20.0) -> Dict[str, np.ndarray]:
+    """
+    Hand-built, fixture-calibrated "spectral gate" inside the KNS-v1 topology.  No training data exists in this
+    environment; this set only shows that the topology can meet the reference's acceptance envelope
+    (binding/python/test_koala.py:71-114) and gives the tests a non-trivial, deterministic network.
+
+      features  f_k = log P_k - (noise_prior_k + margin); the front-end averages +-`smooth` neighbouring bins.
+      stage 3   layer A: per-bin leaky integrator of tanh(gv f_k) (memory zv); layer B: 40 band units, each a
+                triangular average (half-width `width` bins) of layer A -> tanh(kappa (mean - theta)), memory zvb;
+                head 3: y3_j = sigmoid(a h_j)  = band-level speech presence.
+      stage 4   layer A: leaky integrator (memory z_a) of tanh(g1 f_k + beta (2 y3_band(k) - 1)); layer B: tanh(g2 .);
+                head 4: mask_k = sigmoid(g3 h_k).
+      stages 1-2 carry zero weights (constant heads feeding zero feed-forward weights).
+    Reset gates are held open by their bias (W_hh = 0 everywhere), update gates pinned by their bias.
     """
     t = {name: np.zeros(shape, np.float32) for name, shape in tensor_order()}
-    if noise_log_power is None:
-        noise_log_power = np.full(BINS, -4.0)
-    t["mean"][:] = noise_log_power
+    if threshold is None:
+        threshold = noise_prior() + margin
+    t["mean"][:] = threshold
     t["scale"][:] = 1.0
-    eye = np.zeros((BINS, HIDDEN), np.float32)
-    eye[np.arange(BINS), np.arange(BINS)] = 1.0
-    t["w_in"][:] = eye
-    copy = np.zeros((HIDDEN, G3), np.float32)
-    copy[np.arange(HIDDEN), 2 * HIDDEN + np.arange(HIDDEN)] = 1.0  # candidate n_j <- x_j
+    w_in = np.zeros((BINS, HIDDEN), np.float32)
+    for k in range(BINS):
+        ks = [j for j in range(k - smooth, k + smooth + 1) if 0 <= j < BINS]
+        wt = np.array([smooth + 1 - abs(j - k) for j in ks], np.float64)
+        wt /= wt.sum()
+        for j, v in zip(ks, wt):
+            w_in[j, k] = v
+    t["w_in"][:] = w_in
 
-    def layer(prefix, d_in, x_gain, z_bias):
-        w = np.zeros((d_in + HIDDEN, G3), np.float32)
-        w[d_in:, :] = copy * x_gain
-        t[prefix + "w_ih_" + layer.tag][:] = w
+    def logit(p):
+        return float(np.log(p / (1.0 - p)))
+
+    def gate_bias(z):
         b = np.zeros(G3, np.float32)
-        b[0:HIDDEN] = 8.0  # reset gate open
-        b[HIDDEN:2 * HIDDEN] = z_bias  # update gate: z = sigmoid(z_bias) -> memory
-        t[prefix + "b_ih_" + layer.tag][:] = b
+        b[0:HIDDEN] = 8.0                 # reset gate open
+        b[HIDDEN:2 * HIDDEN] = logit(z)   # h' = (1 - z) n + z h
+        return b
 
-    for s in range(STAGES):
-        d_in = HEADS[s - 1] if s else 0
-        first = s == 0
-        layer.tag = "a"
-        layer("s%d." % s, d_in, 0.35 if first else 1.2, 0.3 if first else -4.0)
-        layer.tag = "b"
-        layer("s%d." % s, 0, 1.2, -4.0)
+    bins = np.arange(BINS)
+    # ---- stage 3: band-level speech presence
+    d_in = HEADS[1]
+    w = np.zeros((d_in + HIDDEN, G3), np.float32)
+    w[d_in + bins, 2 * HIDDEN + bins] = gv
+    t["s2.w_ih_a"][:] = w
+    t["s2.b_ih_a"][:] = gate_bias(zv)
+    w = np.zeros((HIDDEN, G3), np.float32)
+    b = gate_bias(zvb)
+    centers = (np.arange(HEADS[2]) + 0.5) * BINS / HEADS[2]
+    for j in range(HEADS[2]):
+        wt = np.maximum(0.0, 1.0 - np.abs(bins - centers[j]) / width)
+        wt /= wt.sum()
+        w[bins, 2 * HIDDEN + j] = kappa * wt
+        b[2 * HIDDEN + j] = -kappa * theta
+    t["s2.w_ih_b"][:] = w
+    t["s2.b_ih_b"][:] = b
+    head = np.zeros((HIDDEN, HEADS[2]), np.float32)
+    head[np.arange(HEADS[2]), np.arange(HEADS[2])] = a
+    t["s2.w_head"][:] = head
+    # ---- stage 4: per-bin gate biased by its band's speech presence
+    d_in = HEADS[2]
+    w = np.zeros((d_in + HIDDEN, G3), np.float32)
+    w[d_in + np.arange(HIDDEN), 2 * HIDDEN + np.arange(HIDDEN)] = g1
+    b = gate_bias(z_a)
+    band = np.minimum((bins * HEADS[2]) // BINS, HEADS[2] - 1)
+    w[band, 2 * HIDDEN + bins] = 2.0 * beta
+    b[2 * HIDDEN + bins] = -beta
+    t["s3.w_ih_a"][:] = w
+    t["s3.b_ih_a"][:] = b
+    w = np.zeros((HIDDEN, G3), np.float32)
+    w[np.arange(HIDDEN), 2 * HIDDEN + np.arange(HIDDEN)] = g2
+    t["s3.w_ih_b"][:] = w
+    t["s3.b_ih_b"][:] = gate_bias(z_b)
     head = np.zeros((HIDDEN, BINS), np.float32)
-    head[np.arange(BINS), np.arange(BINS)] = 14.0
+    head[bins, bins] = g3
     t["s3.w_head"][:] = head
-    t["s3.b_head"][:] = 0.0
+    return t
+
+
+def make_constant_mask(value: float) -> Dict[str, np.ndarray]:
+    """All-zero network whose final head bias pins every mask bin to sigmoid(value): +30 -> exactly 1.0f
+    (output = input delayed by 256 samples, bit for bit), -30 -> ~1e-13 (silence)."""
+    t = {name: np.zeros(shape, np.float32) for name, shape in tensor_order()}
+    t["scale"][:] = 1.0
+    t["s%d.b_head" % (STAGES - 1)][:] = value
     return t
 
 
@@ -147,9 +198,14 @@ def ensure_params(path: str, kind: str = "random", seed: int = 1234, **kw) -> st
             write_params(path, make_random(seed, **kw))
         elif kind == "gate":
             write_params(path, make_gate(**kw))
+        elif kind == "unity":
+            write_params(path, make_constant_mask(30.0))
+        elif kind == "mute":
+            write_params(path, make_constant_mask(-30.0))
         else:
             raise ValueError("unknown parameter kind `%s`" % kind)
     return path
 
 
-__all__ = ["write_params", "read_params", "make_random", "make_gate", "ensure_params", "tensor_order"]
+__all__ = ["write_params", "read_params", "make_random", "make_gate", "make_constant_mask", "noise_prior", "ensure_params",
+           "tensor_order"]

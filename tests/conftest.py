@@ -1,0 +1,69 @@
+import os
+import sys
+import wave
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+BUILD = os.path.join(ROOT, 'build')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_wav(name):
+    with wave.open(os.path.join(GOLDEN, name), 'rb') as f:
+        assert f.getnchannels() == 1 and f.getsampwidth() == 2 and f.getframerate() == 16000
+        return np.frombuffer(f.readframes(f.getnframes()), dtype=np.int16).copy()
+
+
+def model_file(kind, seed=1234):
+    from koala_amd import params
+    name = '%s_%d.kns' % (kind, seed) if kind == 'random' else '%s.kns' % kind
+    return params.ensure_params(os.path.join(BUILD, name), kind, seed)
+
+
+def synth_streams(num_streams, num_frames, seed=0):
+    from koala_amd.workload import synth_streams as gen
+    return gen(num_streams, num_frames, seed)
+
+
+@pytest.fixture(scope='session')
+def test_pcm():
+    return load_wav('test.wav')
+
+
+@pytest.fixture(scope='session')
+def noise_pcm():
+    return load_wav('noise.wav')
+
+
+@pytest.fixture(scope='session')
+def random_model():
+    return model_file('random', 1234)
+
+
+@pytest.fixture(scope='session')
+def gate_model():
+    return model_file('gate')
+
+
+@pytest.fixture(scope='session')
+def unity_model():
+    return model_file('unity')
+
+
+@pytest.fixture(scope='session')
+def native_library():
+    from koala_amd import _util
+    return _util.build_native()
+
+
+def frame_rms(pcm):
+    return float(np.sqrt(np.mean((np.asarray(pcm, np.float64) / 32768.0) ** 2)))

