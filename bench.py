@@ -143,12 +143,12 @@ def main():
         from oracle import oracle
         ncores = os.cpu_count() or 1
         # calibrate, then size the sample for ~10-20 s of CPU work
-        o = oracle.Oracle(model, 64, oracle.PREC_FP32)
-        xs = x[:64, :4 * 256].copy()
+        o = oracle.Oracle(model, 1024, oracle.PREC_FP32)
+        xs = np.ascontiguousarray(np.tile(base, (16, 1))[:, :8 * 256])
         c0 = time.perf_counter()
         o.process(xs)
-        rate = 64 * 4 / (time.perf_counter() - c0)
-        ns = int(min(1024, max(64, (rate * 12) // (T * 64) * 64)))
+        rate = 1024 * 8 / (time.perf_counter() - c0)
+        ns = int(min(16384, max(64, (rate * 15) // (T * 64) * 64)))
         o = oracle.Oracle(model, ns, oracle.PREC_FP32)
         xs = np.ascontiguousarray(np.tile(base, ((ns + 63) // 64, 1))[:ns])
         c0 = time.perf_counter()

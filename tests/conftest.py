@@ -15,6 +15,14 @@ BUILD = os.path.join(ROOT, 'build')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # PyTorch-ROCm wheels bundle their own HIP/HSA runtime; a process that uses both torch and libpv_koala.so must
+    # let torch load first so that both bind to ONE runtime (two runtimes in a process cannot both open the GPU).
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
 
 
 def load_wav(name):
