@@ -14,6 +14,8 @@
 // compiled with -ffp-contract=off so that no operation is fused or split behind the spec's back.
 #include "kns_kernels.h"
 
+#include <stdlib.h>
+
 namespace kns {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -675,8 +677,188 @@ __global__ __launch_bounds__(256, P::kGruWaves) void gru_kernel(GruArgs g) {
     }
 }
 
+// ---- bf16 recurrent kernel with the layer's W_hh RESIDENT on the CU for all T steps ("persistent RNN"):
+// 459 KiB of B-fragments = 4 waves x 3 unit tiles x 27 blocks in VGPRs (324 registers per lane, one wave per SIMD with
+// the whole 512-register file) + 4 x 27 KiB + 27 KiB in LDS.  Per step a wave then needs only the 16 x 288 bf16 hidden
+// tile from LDS and its 15/12 pre-activation tiles from HBM: no weight traffic at all after the prologue.
+// Gate nonlinearities use the hardware transcendentals (v_exp_f32, v_rcp_f32): the bf16 configuration is specified to a
+// tolerance, not bit for bit.
+
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.88539008177792681f));
+}
+
+constexpr int kResTileBytes = 3 * PBF16::NBH * 1024;  // one unit tile of W_hh: 3 gates x 9 k-blocks x 1 KiB
+constexpr int kResBiasBytes = kGateTiles * 16 * 4;
+constexpr int kResLds = 2 * PBF16::NBH * 1024 + 5 * kResTileBytes + kResBiasBytes;  // h double buffer, 4 + 1 tiles, b_hh
+
+// MFMA whose B operand (a weight fragment) lives in the accumulator half of the register file.  hipcc keeps values
+// it loaded itself in VGPRs and reaches AGPRs only through v_accvgpr copies; an "a" constraint on every use is what
+// pins a fragment to AGPRs for the whole kernel.  s_nop 1 covers a VALU write of %0/%1 just before the statement.
+__device__ __forceinline__ void mma_agpr_b(f32x4 &acc, bf16x8 a, const bf16x8 &w) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(w));
+}
+// 16 wait states between the last asm MFMA of a chain and the first VALU read of its accumulators
+__device__ __forceinline__ void mma_agpr_fence(f32x4 &a0, f32x4 &a1, f32x4 &a2) {
+    asm volatile("s_nop 15" : "+v"(a0), "+v"(a1), "+v"(a2));
+}
+
+__global__ __launch_bounds__(256, 1) void gru_resident_kernel(GruArgs g) {
+    typedef PBF16 P;
+    typedef P::frag_t frag_t;
+    constexpr int NBH = P::NBH;
+    __shared__ __attribute__((aligned(16))) char smem[kResLds];
+    char *hbuf0 = smem, *hbuf1 = smem + NBH * 1024;
+    char *wl = smem + 2 * NBH * 1024;
+    float *lbias = (float *) (smem + 2 * NBH * 1024 + 5 * kResTileBytes);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = blockIdx.x;
+    const int colq = lane & 15, rowq = (lane >> 4) * 4;
+    const frag_t *whh = (const frag_t *) g.whh;
+
+    // ---- prologue: this wave's 5 (4) unit tiles of W_hh -> VGPRs (tile 0), AGPRs (tiles 1, 2), LDS (tiles 3, 4)
+    frag_t wv[3][NBH];
+    frag_t wa[2][3][NBH];
+#pragma unroll
+    for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+        for (int blk = 0; blk < NBH; ++blk) wv[gt][blk] = whh[((size_t) (wave * 3 + gt) * NBH + blk) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+            for (int blk = 0; blk < NBH; ++blk) {
+                frag_t w = whh[((size_t) ((wave + 4 * (q + 1)) * 3 + gt) * NBH + blk) * 64 + lane];
+                asm volatile("" : "+a"(w));
+                wa[q][gt][blk] = w;
+            }
+    frag_t *wl3 = (frag_t *) (wl + wave * kResTileBytes);  // unit tile wave + 12, private to this wave
+    frag_t *wl4 = (frag_t *) (wl + 4 * kResTileBytes);     // unit tile 16, wave 0 only
+    for (int i = 0; i < 3 * NBH; ++i) wl3[i * 64 + lane] = whh[((size_t) (wave + 12) * 3 * NBH + i) * 64 + lane];
+    if (wave == 0)
+        for (int i = 0; i < 3 * NBH; ++i) wl4[i * 64 + lane] = whh[((size_t) 16 * 3 * NBH + i) * 64 + lane];
+    for (int i = tid; i < kGateTiles * 16; i += 256) lbias[i] = g.bhh[i];
+
+    f32x4 hreg[kGruTilesPerWave];
+#pragma unroll
+    for (int q = 0; q < kGruTilesPerWave; ++q) {
+        const int u = wave + 4 * q;
+        hreg[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (u < kUnitTiles) hreg[q] = ((const f32x4 *) g.hstate)[((size_t) mt * kUnitTiles + u) * 64 + lane];
+    }
+    for (int i = tid; i < 2 * NBH * 64; i += 256) ((uint4 *) smem)[i] = uint4{0, 0, 0, 0};
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kGruTilesPerWave; ++q) {
+        const int u = wave + 4 * q;
+        if (u < kUnitTiles) {
+            const int k = u * 16 + colq;
+            uint16_t *dst = (uint16_t *) hbuf0 + (k / P::KB) * 64 * P::EPL;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[P::off(rowq + i, k % P::KB)] = P::cvt(hreg[q][i]);
+        }
+    }
+    // pre-activations of step 0
+    P::gi_t gi[kGruTilesPerWave][3];
+    {
+        const P::gi_t *gp = (const P::gi_t *) g.gi + (size_t) mt * kGateTiles * 64;
+#pragma unroll
+        for (int q = 0; q < kGruTilesPerWave; ++q)
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt) {
+                const int u = wave + 4 * q;
+                if (u < kUnitTiles) gi[q][gt] = gp[(u * 3 + gt) * 64 + lane];
+            }
+    }
+    __syncthreads();
+
+    for (int t = 0; t < g.T; ++t) {
+        const char *hc = (t & 1) ? hbuf1 : hbuf0;
+        char *hn = (t & 1) ? hbuf0 : hbuf1;
+        frag_t a[NBH];
+#pragma unroll
+        for (int blk = 0; blk < NBH; ++blk) a[blk] = ((const frag_t *) hc)[blk * 64 + lane];
+        if (t > 0) {  // LDS holds h_{t-1}: publish it as the next layer's A operand
+            frag_t *hs = (frag_t *) g.hseq + ((size_t) (t - 1) * g.mtiles + mt) * NBH * 64;
+#pragma unroll
+            for (int blk = 0; blk < NBH; ++blk)
+                if ((blk & 3) == wave) hs[blk * 64 + lane] = a[blk];
+        }
+        const P::gi_t *gnext =
+            (const P::gi_t *) g.gi + ((size_t) (t + 1 < g.T ? t + 1 : t) * g.mtiles + mt) * kGateTiles * 64;
+#pragma unroll
+        for (int q = 0; q < kGruTilesPerWave; ++q) {
+            const int u = wave + 4 * q;
+            if (q < 4 || wave == 0) {
+                f32x4 acc[3];
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (q == 1 || q == 2) {
+#pragma unroll
+                    for (int blk = 0; blk < NBH; ++blk)
+#pragma unroll
+                        for (int gt = 0; gt < 3; ++gt) mma_agpr_b(acc[gt], a[blk], wa[q == 2 ? 1 : 0][gt][blk]);
+                    mma_agpr_fence(acc[0], acc[1], acc[2]);
+                } else {
+#pragma unroll
+                    for (int blk = 0; blk < NBH; ++blk) {
+#pragma unroll
+                        for (int gt = 0; gt < 3; ++gt) {
+                            frag_t b;
+                            if (q == 0)
+                                b = wv[gt][blk];
+                            else if (q == 3)
+                                b = wl3[(gt * NBH + blk) * 64 + lane];
+                            else
+                                b = wl4[(gt * NBH + blk) * 64 + lane];
+                            acc[gt] = P::mma(a[blk], b, acc[gt]);
+                        }
+                    }
+                }
+                f32x4 ir = P::from_gi(gi[q][0]), iz = P::from_gi(gi[q][1]), in = P::from_gi(gi[q][2]);
+                // this tile's pre-activations of the next step: in flight while the other tiles compute
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt) gi[q][gt] = gnext[(u * 3 + gt) * 64 + lane];
+                const float br = lbias[(u * 3 + 0) * 16 + colq], bz = lbias[(u * 3 + 1) * 16 + colq],
+                            bn = lbias[(u * 3 + 2) * 16 + colq];
+                const int k = u * 16 + colq;
+                uint16_t *dst = (uint16_t *) hn + (k / P::KB) * 64 * P::EPL;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float r = fast_sigmoid(ir[i] + (acc[0][i] + br));
+                    float z = fast_sigmoid(iz[i] + (acc[1][i] + bz));
+                    float n = fast_tanh(__builtin_fmaf(r, acc[2][i] + bn, in[i]));
+                    float h = __builtin_fmaf(z, hreg[q][i] - n, n);
+                    hreg[q][i] = h;
+                    dst[P::off(rowq + i, k % P::KB)] = P::cvt(h);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    {
+        const char *hc = (g.T & 1) ? hbuf1 : hbuf0;
+        frag_t *hs = (frag_t *) g.hseq + ((size_t) (g.T - 1) * g.mtiles + mt) * NBH * 64;
+        for (int blk = wave; blk < NBH; blk += 4) hs[blk * 64 + lane] = ((const frag_t *) hc)[blk * 64 + lane];
+    }
+#pragma unroll
+    for (int q = 0; q < kGruTilesPerWave; ++q) {
+        const int u = wave + 4 * q;
+        if (u < kUnitTiles) ((f32x4 *) g.hstate)[((size_t) mt * kUnitTiles + u) * 64 + lane] = hreg[q];
+    }
+}
+
 void launch_gru(const GruArgs &a, hipStream_t s) {
-    if (a.precision == kBf16)
+    static const bool stream_weights = getenv("KOALA_AMD_GRU_STREAM") != nullptr;  // A/B switch for profiling
+    if (a.precision == kBf16 && !stream_weights)
+        hipLaunchKernelGGL(gru_resident_kernel, dim3(a.mtiles), dim3(256), 0, s, a);
+    else if (a.precision == kBf16)
         hipLaunchKernelGGL(gru_kernel<PBF16>, dim3(a.mtiles), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL(gru_kernel<PF32>, dim3(a.mtiles), dim3(256), 0, s, a);
