@@ -18,6 +18,15 @@
 
 namespace kns {
 
+#ifdef KNS_TIMING
+__device__ unsigned long long g_kns_timing[64];
+#define KNS_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && t == 5) g_kns_timing[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define KNS_STAMP_WS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && mt == 5 * (int) gridDim.x) g_kns_timing[16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define KNS_STAMP(i) do { } while (0)
+#define KNS_STAMP_WS(i) do { } while (0)
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -539,6 +548,187 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 }
 
+constexpr int kGruTilesPerWave = 5;  // 17 unit tiles over 4 waves: 5,4,4,4
+
+// ---- bf16 recurrent kernel with the layer's W_hh RESIDENT on the CU for all T steps ("persistent RNN"):
+// 459 KiB of B-fragments = 4 waves x 3 unit tiles x 27 blocks in VGPRs (324 registers per lane, one wave per SIMD with
+// the whole 512-register file) + 4 x 27 KiB + 27 KiB in LDS.  Per step a wave then needs only the 16 x 288 bf16 hidden
+// tile from LDS and its 15/12 pre-activation tiles from HBM: no weight traffic at all after the prologue.
+// Gate nonlinearities use the hardware transcendentals (v_exp_f32, v_rcp_f32): the bf16 configuration is specified to a
+// tolerance, not bit for bit (DESIGN.md section 2.5).
+
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.88539008177792681f));
+}
+
+constexpr int kResTileBytes = 3 * PBF16::NBH * 1024;  // one unit tile of W_hh: 3 gates x 9 k-blocks x 1 KiB
+constexpr int kResBiasBytes = kGateTiles * 16 * 4;
+constexpr int kResLds = 2 * PBF16::NBH * 1024 + 5 * kResTileBytes + kResBiasBytes;  // h double buffer, 4 + 1 tiles, b_hh
+
+// hipcc keeps values it loaded itself in VGPRs and reaches the accumulator half of the register file only through
+// v_accvgpr copies.  Passing a fragment once through an "a"-constrained empty asm re-defines it as an AGPR value; the
+// MFMA builtins then take it as an AGPR source operand directly, so 216 registers of weights cost no VGPR and no copy.
+__device__ __forceinline__ bf16x8 pin_to_agpr(bf16x8 w) {
+    asm volatile("" : "+a"(w));
+    return w;
+}
+
+// acc[gt] += a[blk] . W for one LDS-resident unit tile stored as [k-block][gate][lane]; the explicit queue keeps
+// kQueue ds_read_b128 in flight so that LDS latency is not paid per MFMA
+template <int NBH, int kQueue>
+__device__ __forceinline__ void mma_lds_tile(f32x4 (&acc)[3], const bf16x8 (&a)[NBH], const bf16x8 *wl, int lane) {
+    constexpr int N = 3 * NBH;
+    bf16x8 qb[kQueue];
+#pragma unroll
+    for (int p = 0; p < kQueue; ++p) qb[p] = wl[p * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);  // pin the order: without it hipcc sinks each read next to its MFMA
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const bf16x8 b = qb[i % kQueue];
+        if (i + kQueue < N) qb[i % kQueue] = wl[(i + kQueue) * 64 + lane];
+        acc[i % 3] = PBF16::mma(a[i / 3], b, acc[i % 3]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---- weight-stationary form of the GRU input-side GEMM (bf16):  Gi = [y_prev ; e] . W_ih + b_ih  over ALL stream-frames.
+// The 51 x 9 e-part blocks of W_ih stay on the CU exactly as W_hh does in gru_resident_kernel (VGPR / AGPR / LDS per
+// wave); the y_prev part (0..2 k-blocks) is re-read from L2 per m-tile.  A persistent workgroup walks over m-tiles:
+// A fragments come straight from HBM in fragment order (no LDS, no barrier), C tiles leave as fp16 fragments.
+// HBM traffic per m-tile is the algorithmic minimum: 9-11 KiB in, 25.5 KiB out.
+constexpr int kWsABlocks = PBF16::NBH + 2;                               // k-blocks of one A tile (y part <= 2)
+constexpr int kWsLds = 5 * kResTileBytes + 2 * kWsABlocks * 1024;        // weight tiles 3, 4 + A double buffer
+
+template <int NB0>
+__global__ __launch_bounds__(256, 1) void gemm_ws_kernel(GemmArgs g) {
+    typedef PBF16 P;
+    typedef P::frag_t frag_t;
+    constexpr int NBH = P::NBH;
+    __shared__ __attribute__((aligned(16))) char smem[kWsLds];
+    frag_t *abuf = (frag_t *) (smem + 5 * kResTileBytes);  // [2][kWsABlocks][64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int colq = lane & 15;
+    constexpr int nb0 = NB0, nb = NB0 + NBH;
+    const frag_t *w = (const frag_t *) g.w;
+
+    frag_t wv[3][NBH];
+    frag_t wa[2][3][NBH];
+#pragma unroll
+    for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+        for (int blk = 0; blk < NBH; ++blk) wv[gt][blk] = w[((size_t) (wave * 3 + gt) * nb + nb0 + blk) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+            for (int blk = 0; blk < NBH; ++blk) {
+                wa[q][gt][blk] = pin_to_agpr(w[((size_t) ((wave + 4 * (q + 1)) * 3 + gt) * nb + nb0 + blk) * 64 + lane]);
+            }
+    frag_t *wl3 = (frag_t *) (smem + wave * kResTileBytes);
+    frag_t *wl4 = (frag_t *) (smem + 4 * kResTileBytes);
+    for (int gt = 0; gt < 3; ++gt)
+        for (int blk = 0; blk < NBH; ++blk)
+            wl3[(blk * 3 + gt) * 64 + lane] = w[((size_t) ((wave + 12) * 3 + gt) * nb + nb0 + blk) * 64 + lane];
+    if (wave == 0)
+        for (int gt = 0; gt < 3; ++gt)
+            for (int blk = 0; blk < NBH; ++blk)
+                wl4[(blk * 3 + gt) * 64 + lane] = w[((size_t) (16 * 3 + gt) * nb + nb0 + blk) * 64 + lane];
+    float bias[kGruTilesPerWave][3];
+#pragma unroll
+    for (int q = 0; q < kGruTilesPerWave; ++q)
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt) {
+            const int u = wave + 4 * q;
+            bias[q][gt] = u < kUnitTiles ? g.bias[(u * 3 + gt) * 16 + colq] : 0.0f;
+        }
+
+    // A tile staging: block j of an m-tile (j < nb0: y part, else e part) is fetched by wave j & 3
+    const frag_t *a0p = (const frag_t *) g.a0;
+    const frag_t *a1p = (const frag_t *) g.a1;
+    auto fetch = [&](int mtile, int j) -> frag_t {
+        return j < nb0 ? a0p[((size_t) mtile * nb0 + j) * 64 + lane] : a1p[((size_t) mtile * NBH + (j - nb0)) * 64 + lane];
+    };
+    int mt = blockIdx.x;
+    if (mt < g.mtiles)
+        for (int j = wave; j < nb; j += 4) abuf[j * 64 + lane] = fetch(mt, j);
+    __syncthreads();
+
+    int cur = 0;
+    for (; mt < g.mtiles; mt += gridDim.x) {
+        KNS_STAMP_WS(0);
+        const int mn = mt + gridDim.x;
+        frag_t stage[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int j = wave + 4 * i;
+            if (mn < g.mtiles && j < nb) stage[i] = fetch(mn, j);  // in flight during this tile's MFMAs
+        }
+        const frag_t *ab = abuf + cur * kWsABlocks * 64;
+        frag_t cy[NB0 > 0 ? NB0 : 1], ce[NBH];
+#pragma unroll
+        for (int blk = 0; blk < NB0; ++blk) cy[blk] = ab[blk * 64 + lane];
+#pragma unroll
+        for (int blk = 0; blk < NBH; ++blk) ce[blk] = ab[(nb0 + blk) * 64 + lane];
+        KNS_STAMP_WS(1);
+        P::gi_t *out = (P::gi_t *) g.out + (size_t) mt * kGateTiles * 64;
+#pragma unroll
+        for (int q = 0; q < kGruTilesPerWave; ++q) {
+            const int u = wave + 4 * q;
+            {
+                f32x4 acc[3];
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (NB0 > 0) {
+                    frag_t wy[NB0 > 0 ? NB0 : 1][3];
+                    __builtin_amdgcn_sched_barrier(0);  // keep the streamed y-part loads of other tiles out of here
+#pragma unroll
+                    for (int blk = 0; blk < NB0; ++blk)
+#pragma unroll
+                        for (int gt = 0; gt < 3; ++gt)
+                            wy[blk][gt] = w[((size_t) ((u < kUnitTiles ? u : 0) * 3 + gt) * nb + blk) * 64 + lane];
+#pragma unroll
+                    for (int blk = 0; blk < NB0; ++blk)
+#pragma unroll
+                        for (int gt = 0; gt < 3; ++gt) acc[gt] = P::mma(cy[blk], wy[blk][gt], acc[gt]);
+                }
+                if (q < 3) {
+#pragma unroll
+                    for (int blk = 0; blk < NBH; ++blk)
+#pragma unroll
+                        for (int gt = 0; gt < 3; ++gt)
+                            acc[gt] = P::mma(ce[blk], q == 0 ? wv[gt][blk] : wa[q == 2 ? 1 : 0][gt][blk], acc[gt]);
+                } else {
+                    mma_lds_tile<NBH, 4>(acc, ce, q == 3 ? wl3 : wl4, lane);
+                }
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt) {
+                    f32x4 v = acc[gt];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[q][gt];
+                    if (q < 4 || wave == 0) out[(u * 3 + gt) * 64 + lane] = P::to_gi(v);
+                }
+                KNS_STAMP_WS(2 + q);
+            }
+        }
+        frag_t *an = abuf + (cur ^ 1) * kWsABlocks * 64;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int j = wave + 4 * i;
+            if (mn < g.mtiles && j < nb) an[j * 64 + lane] = stage[i];
+        }
+        KNS_STAMP_WS(7);
+        __syncthreads();
+        KNS_STAMP_WS(8);
+        cur ^= 1;
+    }
+}
+
 template <class P>
 static void launch_gemm_p(const GemmArgs &a, hipStream_t s) {
     const int nb = a.nb0 + a.nb1;
@@ -559,6 +749,17 @@ static void launch_gemm_p(const GemmArgs &a, hipStream_t s) {
 }
 
 void launch_gemm(const GemmArgs &a, hipStream_t s) {
+    static const bool no_ws = getenv("KOALA_AMD_GEMM_GENERIC") != nullptr;  // A/B switch for profiling
+    if (a.precision == kBf16 && a.out_kind == kOutGi && a.ntiles == kGateTiles && a.nb1 == PBF16::NBH && a.nb0 <= 2 &&
+        a.mtiles >= 256 && !no_ws) {
+        if (a.nb0 == 0)
+            hipLaunchKernelGGL(gemm_ws_kernel<0>, dim3(256), dim3(256), 0, s, a);
+        else if (a.nb0 == 1)
+            hipLaunchKernelGGL(gemm_ws_kernel<1>, dim3(256), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(gemm_ws_kernel<2>, dim3(256), dim3(256), 0, s, a);
+        return;
+    }
     if (a.precision == kBf16)
         launch_gemm_p<PBF16>(a, s);
     else
@@ -566,8 +767,6 @@ void launch_gemm(const GemmArgs &a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------ recurrent GRU
-
-constexpr int kGruTilesPerWave = 5;  // 17 unit tiles over 4 waves: 5,4,4,4
 
 template <class P>
 __global__ __launch_bounds__(256, P::kGruWaves) void gru_kernel(GruArgs g) {
@@ -677,35 +876,6 @@ __global__ __launch_bounds__(256, P::kGruWaves) void gru_kernel(GruArgs g) {
     }
 }
 
-// ---- bf16 recurrent kernel with the layer's W_hh RESIDENT on the CU for all T steps ("persistent RNN"):
-// 459 KiB of B-fragments = 4 waves x 3 unit tiles x 27 blocks in VGPRs (324 registers per lane, one wave per SIMD with
-// the whole 512-register file) + 4 x 27 KiB + 27 KiB in LDS.  Per step a wave then needs only the 16 x 288 bf16 hidden
-// tile from LDS and its 15/12 pre-activation tiles from HBM: no weight traffic at all after the prologue.
-// Gate nonlinearities use the hardware transcendentals (v_exp_f32, v_rcp_f32): the bf16 configuration is specified to a
-// tolerance, not bit for bit (DESIGN.md section 2.5).
-
-__device__ __forceinline__ float fast_sigmoid(float x) {
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
-}
-__device__ __forceinline__ float fast_tanh(float x) {
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.88539008177792681f));
-}
-
-constexpr int kResTileBytes = 3 * PBF16::NBH * 1024;  // one unit tile of W_hh: 3 gates x 9 k-blocks x 1 KiB
-constexpr int kResBiasBytes = kGateTiles * 16 * 4;
-constexpr int kResLds = 2 * PBF16::NBH * 1024 + 5 * kResTileBytes + kResBiasBytes;  // h double buffer, 4 + 1 tiles, b_hh
-
-// MFMA whose B operand (a weight fragment) lives in the accumulator half of the register file.  hipcc keeps values
-// it loaded itself in VGPRs and reaches AGPRs only through v_accvgpr copies; an "a" constraint on every use is what
-// pins a fragment to AGPRs for the whole kernel.  s_nop 1 covers a VALU write of %0/%1 just before the statement.
-__device__ __forceinline__ void mma_agpr_b(f32x4 &acc, bf16x8 a, const bf16x8 &w) {
-    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(w));
-}
-// 16 wait states between the last asm MFMA of a chain and the first VALU read of its accumulators
-__device__ __forceinline__ void mma_agpr_fence(f32x4 &a0, f32x4 &a1, f32x4 &a2) {
-    asm volatile("s_nop 15" : "+v"(a0), "+v"(a1), "+v"(a2));
-}
-
 __global__ __launch_bounds__(256, 1) void gru_resident_kernel(GruArgs g) {
     typedef PBF16 P;
     typedef P::frag_t frag_t;
@@ -734,15 +904,15 @@ __global__ __launch_bounds__(256, 1) void gru_resident_kernel(GruArgs g) {
         for (int gt = 0; gt < 3; ++gt)
 #pragma unroll
             for (int blk = 0; blk < NBH; ++blk) {
-                frag_t w = whh[((size_t) ((wave + 4 * (q + 1)) * 3 + gt) * NBH + blk) * 64 + lane];
-                asm volatile("" : "+a"(w));
-                wa[q][gt][blk] = w;
+                wa[q][gt][blk] = pin_to_agpr(whh[((size_t) ((wave + 4 * (q + 1)) * 3 + gt) * NBH + blk) * 64 + lane]);
             }
     frag_t *wl3 = (frag_t *) (wl + wave * kResTileBytes);  // unit tile wave + 12, private to this wave
     frag_t *wl4 = (frag_t *) (wl + 4 * kResTileBytes);     // unit tile 16, wave 0 only
-    for (int i = 0; i < 3 * NBH; ++i) wl3[i * 64 + lane] = whh[((size_t) (wave + 12) * 3 * NBH + i) * 64 + lane];
-    if (wave == 0)
-        for (int i = 0; i < 3 * NBH; ++i) wl4[i * 64 + lane] = whh[((size_t) 16 * 3 * NBH + i) * 64 + lane];
+    for (int gt = 0; gt < 3; ++gt)
+        for (int blk = 0; blk < NBH; ++blk) {
+            wl3[(blk * 3 + gt) * 64 + lane] = whh[((size_t) ((wave + 12) * 3 + gt) * NBH + blk) * 64 + lane];
+            if (wave == 0) wl4[(blk * 3 + gt) * 64 + lane] = whh[((size_t) (16 * 3 + gt) * NBH + blk) * 64 + lane];
+        }
     for (int i = tid; i < kGateTiles * 16; i += 256) lbias[i] = g.bhh[i];
 
     f32x4 hreg[kGruTilesPerWave];
@@ -779,6 +949,7 @@ __global__ __launch_bounds__(256, 1) void gru_resident_kernel(GruArgs g) {
     __syncthreads();
 
     for (int t = 0; t < g.T; ++t) {
+        KNS_STAMP(0);
         const char *hc = (t & 1) ? hbuf1 : hbuf0;
         char *hn = (t & 1) ? hbuf0 : hbuf1;
         frag_t a[NBH];
@@ -790,6 +961,7 @@ __global__ __launch_bounds__(256, 1) void gru_resident_kernel(GruArgs g) {
             for (int blk = 0; blk < NBH; ++blk)
                 if ((blk & 3) == wave) hs[blk * 64 + lane] = a[blk];
         }
+        KNS_STAMP(1);
         const P::gi_t *gnext =
             (const P::gi_t *) g.gi + ((size_t) (t + 1 < g.T ? t + 1 : t) * g.mtiles + mt) * kGateTiles * 64;
 #pragma unroll
@@ -799,27 +971,14 @@ __global__ __launch_bounds__(256, 1) void gru_resident_kernel(GruArgs g) {
                 f32x4 acc[3];
 #pragma unroll
                 for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (q == 1 || q == 2) {
+                if (q < 3) {
 #pragma unroll
                     for (int blk = 0; blk < NBH; ++blk)
 #pragma unroll
-                        for (int gt = 0; gt < 3; ++gt) mma_agpr_b(acc[gt], a[blk], wa[q == 2 ? 1 : 0][gt][blk]);
-                    mma_agpr_fence(acc[0], acc[1], acc[2]);
+                        for (int gt = 0; gt < 3; ++gt)
+                            acc[gt] = P::mma(a[blk], q == 0 ? wv[gt][blk] : wa[q == 2 ? 1 : 0][gt][blk], acc[gt]);
                 } else {
-#pragma unroll
-                    for (int blk = 0; blk < NBH; ++blk) {
-#pragma unroll
-                        for (int gt = 0; gt < 3; ++gt) {
-                            frag_t b;
-                            if (q == 0)
-                                b = wv[gt][blk];
-                            else if (q == 3)
-                                b = wl3[(gt * NBH + blk) * 64 + lane];
-                            else
-                                b = wl4[(gt * NBH + blk) * 64 + lane];
-                            acc[gt] = P::mma(a[blk], b, acc[gt]);
-                        }
-                    }
+                    mma_lds_tile<NBH, 6>(acc, a, q == 3 ? wl3 : wl4, lane);
                 }
                 f32x4 ir = P::from_gi(gi[q][0]), iz = P::from_gi(gi[q][1]), in = P::from_gi(gi[q][2]);
                 // this tile's pre-activations of the next step: in flight while the other tiles compute
@@ -838,9 +997,12 @@ __global__ __launch_bounds__(256, 1) void gru_resident_kernel(GruArgs g) {
                     hreg[q][i] = h;
                     dst[P::off(rowq + i, k % P::KB)] = P::cvt(h);
                 }
+                KNS_STAMP(2 + q);
             }
         }
+        KNS_STAMP(7);
         __syncthreads();
+        KNS_STAMP(8);
     }
     {
         const char *hc = (g.T & 1) ? hbuf1 : hbuf0;
@@ -879,6 +1041,10 @@ __global__ void reset_kernel(ResetArgs g) {
         g.hstate[(((size_t) layer * mtiles + mt) * kUnitTiles + u) * 256 + cpack_off(row, col)] = 0.0f;
     }
 }
+
+#ifdef KNS_TIMING
+void read_timing(unsigned long long *out) { (void) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kns_timing), sizeof(unsigned long long) * 64); }
+#endif
 
 void launch_reset(const ResetArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(reset_kernel, dim3(a.Bpad), dim3(256), 0, s, a);

@@ -19,6 +19,12 @@
 #include "../../include/pv_koala_batch.h"
 #include "kns_engine.h"
 
+#ifdef KNS_TIMING
+namespace kns {
+void read_timing(unsigned long long *out);
+}
+#endif
+
 namespace {
 
 const char kBuildId[] = "a355c0a";  // 7 hex digits, as the reference prints in front of every message
@@ -474,5 +480,9 @@ PV_API int64_t pv_koala_batch_debug_read(pv_koala_batch_t *object, int32_t what,
     }
     return n;
 }
+
+#ifdef KNS_TIMING
+PV_API void pv_koala_debug_timing(unsigned long long *out) { kns::read_timing(out); }
+#endif
 
 }  // extern "C"

@@ -13,13 +13,13 @@ def main(path, out=None):
     for name, calls, total, avg, pct in rows:
         lines.append('%-72s %8d %14d %12.0f %7.2f' % (name[:72], calls, total, avg, pct))
     try:
-        pmc = c.execute("select k.name, p.counter_name, sum(p.value), count(*) from pmc_events p "
-                        "join kernels k on k.dispatch_id = p.dispatch_id group by k.name, p.counter_name").fetchall()
+        pmc = c.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection "
+                        "group by kernel_name, counter_name").fetchall()
     except Exception:
         pmc = []
     if pmc:
         lines.append('')
-        lines.append('%-60s %-24s %18s %8s' % ('kernel', 'counter', 'sum', 'n'))
+        lines.append('%-60s %-24s %18s %8s' % ('kernel', 'counter', 'sum over dispatches', 'dispatches'))
         for name, ctr, val, n in pmc:
             lines.append('%-60s %-24s %18.1f %8d' % (name[:60], ctr, val, n))
     text = '\n'.join(lines) + '\n'

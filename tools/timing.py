@@ -1,0 +1,30 @@
+"""Developer tool: in-kernel s_memtime stamps of one recurrent step (needs a -DKNS_TIMING build)."""
+import ctypes as C, os, subprocess, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+lib = os.path.join(ROOT, 'build', 'libpv_koala_timing.so')
+os.makedirs(os.path.dirname(lib), exist_ok=True)
+src = [os.path.join(ROOT, 'koala_amd', 'csrc', f) for f in ('kns_kernels.hip', 'kns_engine.cpp', 'pv_api.cpp')]
+subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
+                       '-ffp-contract=off', '-DKNS_TIMING', '-x', 'hip'] + src + ['-shared', '-o', lib])
+import koala_amd
+from koala_amd import params
+from koala_amd.workload import synth_streams
+model = params.ensure_params(os.path.join(ROOT, 'build', 'random_1234.kns'), 'random', 1234)
+B, T = 4096, 32
+x = torch.from_numpy(np.tile(synth_streams(64, T, 1), (B // 64, 1))).cuda()
+y = torch.empty_like(x)
+kb = koala_amd.create_batch('k', B, T, 'bf16', model_path=model, library_path=lib)
+for _ in range(3):
+    kb.process_device(T, x.data_ptr(), y.data_ptr())
+kb.synchronize()
+l = C.CDLL(lib)
+buf = (C.c_ulonglong * 64)()
+l.pv_koala_debug_timing(buf)
+t = np.array(buf[:9], dtype=np.int64)
+w = np.array(buf[16:25], dtype=np.int64)
+print('ws gemm:', {n: int(d) for n, d in zip(['stage issue + A read', 'tile0', 'tile1', 'tile2', 'tile3', 'tile4', 'stage write', 'barrier'], np.diff(w))})
+print('stamps (s_memtime ticks rel.):', (t - t[0]).tolist())
+names = ['A frags read', 'tile0', 'tile1', 'tile2', 'tile3', 'tile4', 'pre-barrier', 'barrier']
+print({n: int(d) for n, d in zip(names, np.diff(t))})
