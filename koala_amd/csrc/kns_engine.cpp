@@ -281,7 +281,8 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     const size_t mtb = (size_t) Bpad_ / 16;
     d_hist_[0] = (int16_t *) dalloc((size_t) Bpad_ * kFrame * 2, true);
     d_hist_[1] = (int16_t *) dalloc((size_t) Bpad_ * kFrame * 2, true);
-    d_tail_ = (float *) dalloc((size_t) Bpad_ * kFrame * 4, true);
+    d_tail_[0] = (float *) dalloc((size_t) Bpad_ * kFrame * 4, true);
+    d_tail_[1] = (float *) dalloc((size_t) Bpad_ * kFrame * 4, true);
     d_hstate_ = (float *) dalloc((size_t) kGruLayers * mtb * kUnitTiles * 1024, true);
     d_rmask_ = (uint8_t *) dalloc((size_t) Bpad_, true);
 
@@ -399,7 +400,8 @@ bool Engine::reset(const uint8_t *host_mask, std::string *err) {
     ResetArgs r;
     r.hist = d_hist_[0];
     r.hist2 = d_hist_[1];
-    r.tail = d_tail_;
+    r.tail = d_tail_[0];
+    r.tail2 = d_tail_[1];
     r.hstate = d_hstate_;
     r.Bpad = Bpad_;
     r.mask = nullptr;
@@ -500,7 +502,9 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     sy.mask = d_mask_;
     sy.window = d_window_;
     sy.twiddle = d_twiddle_;
-    sy.tail = d_tail_;
+    sy.tail_in = d_tail_[tail_cur_];
+    sy.tail_out = d_tail_[tail_cur_ ^ 1];
+    sy.seg = T <= 4 ? T : 4;
     sy.out = d_out;
     sy.B = B_;
     sy.Bpad = Bpad_;
@@ -508,6 +512,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     tick(kClsSynthesis);
     launch_synthesis(sy, stream_);
     tock(kClsSynthesis);
+    tail_cur_ ^= 1;
 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

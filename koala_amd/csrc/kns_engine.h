@@ -79,7 +79,8 @@ private:
     // per-stream state
     int16_t *d_hist_[2] = {nullptr, nullptr};
     int hist_cur_ = 0;
-    float *d_tail_ = nullptr, *d_hstate_ = nullptr;
+    float *d_tail_[2] = {nullptr, nullptr}, *d_hstate_ = nullptr;
+    int tail_cur_ = 0;
     uint8_t *d_rmask_ = nullptr;
 
     // activation workspace (fragment layouts)

@@ -29,9 +29,11 @@ struct SynthesisArgs {
     const float *mask;      // C-packed fp32 [T*mtiles][17][64][4]
     const float *window;    // [512]
     const float *twiddle;   // [512][2]
-    float *tail;            // [Bpad][256] overlap-add state (in/out)
+    const float *tail_in;   // [Bpad][256] overlap-add state left by the previous call
+    float *tail_out;        // [Bpad][256] state after this call (ping-pong with tail_in)
     int16_t *out;           // [B][T*256]
     int B, Bpad, T;
+    int seg;                // frames per workgroup; segments after the first replay one frame to rebuild the tail
 };
 void launch_synthesis(const SynthesisArgs &a, hipStream_t s);
 
@@ -70,7 +72,8 @@ void launch_gru(const GruArgs &a, hipStream_t s);
 struct ResetArgs {
     int16_t *hist;   // [Bpad][256] (both ping-pong copies are cleared)
     int16_t *hist2;
-    float *tail;     // [Bpad][256]
+    float *tail;     // [Bpad][256] (both ping-pong copies are cleared)
+    float *tail2;
     float *hstate;   // [8][mtiles][17][64][4]
     const uint8_t *mask;  // [Bpad] device copy, or null for all
     int Bpad;

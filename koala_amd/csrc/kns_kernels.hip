@@ -180,18 +180,24 @@ __device__ __forceinline__ void radix4(cpx (&v)[4]) {
     v[3] = csub(a1, a3);
 }
 
+// LDS exchange buffers of the wave FFT.  Padding them (i -> i + (i >> 5)) removes the 4-way ds_write_b32 conflicts of
+// the first two radix-4 stages but was measured SLOWER on MI355X (synthesis 246 vs 193 us): the extra address VALU
+// costs more than the conflicts, so the buffers are left linear.
+constexpr int kFftPad = 256;               // floats per re / im array
+constexpr int kFftBufFloats = 4 * kFftPad;  // two ping-pong buffers of {re, im}
+__device__ __forceinline__ int fpad(int i) { return i; }
+
 // Forward 256-point complex FFT of one wavefront, radix-4 Stockham autosort.  On entry v[r] = z[lane + 64 r].
-// `buf` is this wave's LDS scratch: two ping-pong buffers of {re[256], im[256]}.  On return the spectrum is in
-// natural order in buf[0..511] (re at [k], im at [256 + k]) and visible to the whole wave.
-// tw = exp(-2 pi i k / 512), k = 0..511, in LDS.
+// `buf` is this wave's LDS scratch (kFftBufFloats).  On return the spectrum is in natural order in the first buffer
+// (re at fpad(k), im at kFftPad + fpad(k)) and visible to the whole wave.  tw = exp(-2 pi i k / 512), k = 0..511, in LDS.
 __device__ __forceinline__ void fft256_wave(cpx (&v)[4], float *buf, const float2 *tw, int lane) {
-    float *b0 = buf, *b1 = buf + 512;
+    float *b0 = buf, *b1 = buf + 2 * kFftPad;
     // stage Ns = 1 (all twiddles are 1)
     radix4(v);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        b1[4 * lane + r] = v[r].x;
-        b1[256 + 4 * lane + r] = v[r].y;
+        b1[fpad(4 * lane + r)] = v[r].x;
+        b1[kFftPad + fpad(4 * lane + r)] = v[r].y;
     }
     wave_lds_sync();
     // stages Ns = 4, 16, 64
@@ -203,8 +209,8 @@ __device__ __forceinline__ void fft256_wave(cpx (&v)[4], float *buf, const float
         const int k = lane & (Ns - 1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            v[r].x = src[lane + 64 * r];
-            v[r].y = src[256 + lane + 64 * r];
+            v[r].x = src[fpad(lane + 64 * r)];
+            v[r].y = src[kFftPad + fpad(lane + 64 * r)];
         }
 #pragma unroll
         for (int r = 1; r < 4; ++r) {
@@ -215,8 +221,8 @@ __device__ __forceinline__ void fft256_wave(cpx (&v)[4], float *buf, const float
         const int j0 = (lane / Ns) * Ns * 4 + k;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            dst[j0 + r * Ns] = v[r].x;
-            dst[256 + j0 + r * Ns] = v[r].y;
+            dst[fpad(j0 + r * Ns)] = v[r].x;
+            dst[kFftPad + fpad(j0 + r * Ns)] = v[r].y;
         }
         wave_lds_sync();
     }
@@ -230,8 +236,8 @@ __global__ __launch_bounds__(256) void analysis_kernel(AnalysisArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *tw = (float2 *) smem;                         // 4 KiB
     float *win = (float *) (smem + 4096);                 // 2 KiB
-    float *fftbuf = (float *) (smem + 6144);              // 4 waves x 4 KiB
-    typename P::elem_t *tile = (typename P::elem_t *) (smem + 6144 + 16384);  // nbf KiB, A-packed feature tile
+    float *fftbuf = (float *) (smem + 6144);              // 4 waves x kFftBufFloats
+    typename P::elem_t *tile = (typename P::elem_t *) (smem + 6144 + 4 * kFftBufFloats * 4);  // nbf KiB, A-packed feature tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mt = blockIdx.x, t = blockIdx.y;
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(256) void analysis_kernel(AnalysisArgs g) {
     }
     __syncthreads();
 
-    float *buf = fftbuf + wave * 1024;
+    float *buf = fftbuf + wave * kFftBufFloats;
     const size_t row_len = (size_t) g.T * kFrame;
 
     for (int f = 0; f < 4; ++f) {
@@ -281,8 +287,8 @@ __global__ __launch_bounds__(256) void analysis_kernel(AnalysisArgs g) {
         for (int r = 0; r < 4; ++r) {
             const int k = lane + 64 * r;
             const int kc = (256 - k) & 255;
-            cpx zk = {buf[k], buf[256 + k]};
-            cpx zc = {buf[kc], -buf[256 + kc]};
+            cpx zk = {buf[fpad(k)], buf[kFftPad + fpad(k)]};
+            cpx zc = {buf[fpad(kc)], -buf[kFftPad + fpad(kc)]};
             float2 w = tw[k];
             cpx s = cadd(zk, zc), d = csub(zk, zc);
             cpx p = cmul(d, cpx{w.x, w.y});
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(256) void analysis_kernel(AnalysisArgs g) {
 
 void launch_analysis(const AnalysisArgs &a, hipStream_t s) {
     dim3 grid(a.Bpad / 16, a.T);
-    size_t lds = 6144 + 16384 + (size_t) a.nbf * 1024;
+    size_t lds = 6144 + 4 * kFftBufFloats * 4 + (size_t) a.nbf * 1024;
     if (a.precision == kBf16)
         hipLaunchKernelGGL(analysis_kernel<PBF16>, grid, dim3(256), lds, s, a);
     else
@@ -325,21 +331,26 @@ void launch_analysis(const AnalysisArgs &a, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------ synthesis
 
+constexpr int kMaskLd = 273;  // row stride (floats) of the row-major mask tile in LDS: odd, so column walks are conflict-free
+
 __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *tw = (float2 *) smem;
     float *win = (float *) (smem + 4096);
     float *fftbuf = (float *) (smem + 6144);
-    float *mtile = (float *) (smem + 6144 + 16384);  // C-packed [17][64][4] fp32
+    float *mrow = (float *) (smem + 6144 + 4 * kFftBufFloats * 4);  // [16][kMaskLd] fp32
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mt = blockIdx.x;
     const int mtiles = g.Bpad >> 4;
+    // this workgroup produces frames [t0, t1) of its 16 streams; a segment that does not start at 0 first replays
+    // frame t0 - 1 (no output) to rebuild the overlap-add tail it inherits
+    const int t0 = blockIdx.y * g.seg, t1 = min(g.T, t0 + g.seg);
     for (int i = tid; i < 512; i += 256) {
         tw[i] = ((const float2 *) g.twiddle)[i];
         win[i] = g.window[i];
     }
-    float *buf = fftbuf + wave * 1024;
+    float *buf = fftbuf + wave * kFftBufFloats;
     const size_t row_len = (size_t) g.T * kFrame;
 
     // overlap-add tail of this wave's four streams: lane holds samples 2n, 2n+1 for n = lane, lane + 64
@@ -347,17 +358,24 @@ __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
         const int b = mt * 16 + wave * 4 + f;
-        const float2 *tp = (const float2 *) (g.tail + (size_t) b * kFrame);
+        const float2 *tp = (const float2 *) (g.tail_in + (size_t) b * kFrame);
         tl[f][0] = tp[lane];
         tl[f][1] = tp[lane + 64];
     }
 
-    for (int t = 0; t < g.T; ++t) {
-        __syncthreads();  // previous frame's readers are done with mtile
+    for (int t = (t0 > 0 ? t0 - 1 : 0); t < t1; ++t) {
+        const bool emit = t >= t0;
+        __syncthreads();  // previous frame's readers are done with the mask tile
         {
-            const uint4 *src = (const uint4 *) g.mask + ((size_t) t * mtiles + mt) * kMaskTiles * 64;
-            uint4 *dst = (uint4 *) mtile;
-            for (int i = tid; i < kMaskTiles * 64; i += 256) dst[i] = src[i];
+            // C-packed fp32 tile [17][64 lanes][4 rows] -> row-major [16][kMaskLd]
+            const f32x4 *src = (const f32x4 *) g.mask + ((size_t) t * mtiles + mt) * kMaskTiles * 64;
+            for (int i = tid; i < kMaskTiles * 64; i += 256) {
+                const f32x4 v = src[i];
+                const int nt = i >> 6, l = i & 63;
+                const int col = nt * 16 + (l & 15), row = (l >> 4) * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mrow[(row + r) * kMaskLd + col] = v[r];
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -365,15 +383,15 @@ __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
             const int row = wave * 4 + f;
             const int b = mt * 16 + row;
             const float2 *spec = (const float2 *) g.spec + ((size_t) t * g.Bpad + b) * 256;
+            const float *mk_row = mrow + row * kMaskLd;
             cpx v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = lane + 64 * r;
                 const int kc = (256 - k) & 255;
                 float2 xk = spec[k], xc = spec[kc];
-                float mk = mtile[(k >> 4) * 256 + cpack_off(row, k & 15)];
-                const int kcm = 256 - k;  // mask index of the mirrored bin (256 when k == 0)
-                float mc = mtile[(kcm >> 4) * 256 + cpack_off(row, kcm & 15)];
+                float mk = mk_row[k];
+                float mc = mk_row[256 - k];  // mirrored bin (256 when k == 0)
                 cpx yk, yc;
                 if (k == 0) {
                     yk = {mk * xk.x, 0.0f};
@@ -395,8 +413,8 @@ __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
             for (int r = 0; r < 4; ++r) {
                 const int n = lane + 64 * r;
                 // swapped output: re <-> im
-                float x0 = buf[256 + n] * (1.0f / 256.0f);
-                float x1 = buf[n] * (1.0f / 256.0f);
+                float x0 = buf[kFftPad + fpad(n)] * (1.0f / 256.0f);
+                float x1 = buf[fpad(n)] * (1.0f / 256.0f);
                 float y0 = x0 * win[2 * n], y1 = x1 * win[2 * n + 1];
                 if (r < 2) {
                     float a0 = (tl[f][r].x + y0) * 32768.0f, a1 = (tl[f][r].y + y1) * 32768.0f;
@@ -407,7 +425,7 @@ __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
                     tl[f][r - 2] = float2{y0, y1};
                 }
             }
-            if (b < g.B) {
+            if (emit && b < g.B) {
                 int *o = (int *) (g.out + (size_t) b * row_len + (size_t) t * kFrame);
                 o[lane] = packed[0];
                 o[lane + 64] = packed[1];
@@ -415,18 +433,20 @@ __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
             wave_lds_sync();
         }
     }
+    if (t1 == g.T) {
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-        const int b = mt * 16 + wave * 4 + f;
-        float2 *tp = (float2 *) (g.tail + (size_t) b * kFrame);
-        tp[lane] = tl[f][0];
-        tp[lane + 64] = tl[f][1];
+        for (int f = 0; f < 4; ++f) {
+            const int b = mt * 16 + wave * 4 + f;
+            float2 *tp = (float2 *) (g.tail_out + (size_t) b * kFrame);
+            tp[lane] = tl[f][0];
+            tp[lane + 64] = tl[f][1];
+        }
     }
 }
 
 void launch_synthesis(const SynthesisArgs &a, hipStream_t s) {
-    size_t lds = 6144 + 16384 + kMaskTiles * 1024;
-    hipLaunchKernelGGL(synthesis_kernel, dim3(a.Bpad / 16), dim3(256), lds, s, a);
+    size_t lds = 6144 + 4 * kFftBufFloats * 4 + 16 * kMaskLd * 4;
+    hipLaunchKernelGGL(synthesis_kernel, dim3(a.Bpad / 16, (a.T + a.seg - 1) / a.seg), dim3(256), lds, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------ GEMM
@@ -1035,6 +1055,7 @@ __global__ void reset_kernel(ResetArgs g) {
     g.hist[(size_t) b * kFrame + tid] = 0;
     g.hist2[(size_t) b * kFrame + tid] = 0;
     g.tail[(size_t) b * kFrame + tid] = 0.0f;
+    g.tail2[(size_t) b * kFrame + tid] = 0.0f;
     const int mtiles = g.Bpad >> 4, mt = b >> 4, row = b & 15;
     for (int i = tid; i < kGruLayers * kUnitTiles * 16; i += 256) {
         const int col = i & 15, u = (i >> 4) % kUnitTiles, layer = (i >> 4) / kUnitTiles;

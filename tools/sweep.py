@@ -18,7 +18,8 @@ for T in [int(t) for t in os.environ.get('SWEEP_T', '1,4,16,32,64').split(',')]:
     base = synth_streams(64, T, seed=1)
     x = torch.from_numpy(np.tile(base, (B // 64, 1))).cuda()
     y = torch.empty_like(x)
-    kb = koala_amd.create_batch('k', B, T, os.environ.get('SWEEP_PREC', 'bf16'), model_path=model)
+    kb = koala_amd.create_batch('k', B, T, os.environ.get('SWEEP_PREC', 'bf16'), model_path=model,
+                               library_path=os.environ.get('SWEEP_LIB'))
     kb.set_stream(torch.cuda.current_stream().cuda_stream)
     for _ in range(3):
         kb.process_device(T, x.data_ptr(), y.data_ptr())
