@@ -135,7 +135,24 @@ def main():
     dominant = max(stages, key=lambda k: stages[k]['avg_launch_ms'] * stages[k]['launches_per_step'])
     roofline = dict(stages[dominant])
     roofline['kernel'] = dominant
-    roofline['traffic'] = None  # HBM bytes from rocprofv3 --pmc passes are recorded in profiles/, not collected live
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command (tools/pmc_run.sh ->
+    # profiles/*_pmc.json; FETCH_SIZE doubled per the gfx950 correction); they cannot be collected inside a timed run
+    roofline['traffic'] = None
+    try:
+        import glob
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json')))
+        if pmc_files and B == 4096 and T == 32 and args.precision == 'bf16':
+            pmc = json.load(open(pmc_files[-1]))
+            for entry in pmc.values():
+                if entry.get('class') == dominant and 'hbm_bytes' in entry:
+                    roofline['traffic'] = entry['hbm_bytes']
+                    roofline['traffic_source'] = os.path.basename(pmc_files[-1])
+            for name in stages:
+                for entry in pmc.values():
+                    if entry.get('class') == name and 'hbm_bytes' in entry:
+                        stages[name]['traffic'] = entry['hbm_bytes']
+    except Exception:
+        pass
 
     # ---- parity spot check inside the bench: the timed engine vs the CPU oracle on a few streams
     cpu = None

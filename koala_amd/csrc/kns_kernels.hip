@@ -243,6 +243,21 @@ __global__ __launch_bounds__(256) void analysis_kernel(AnalysisArgs g) {
     const int mt = blockIdx.x, t = blockIdx.y;
     const int mtiles = g.Bpad >> 4;
 
+    // all 16 sample loads of this wave's four frames go out before anything else: the kernel is latency-bound on them
+    const size_t row_len = (size_t) g.T * kFrame;
+    int raw[4][4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int b = mt * 16 + wave * 4 + f;
+        const int16_t *cur = g.pcm + (size_t) b * row_len + (size_t) t * kFrame;
+        const int16_t *old = (t == 0) ? g.hist_in + (size_t) b * kFrame : cur - kFrame;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = lane + 64 * r;
+            const int16_t *src = (r < 2) ? old + 2 * n : cur + 2 * (n - 128);
+            raw[f][r] = (b < g.B) ? *(const int *) src : 0;
+        }
+    }
     for (int i = tid; i < 512; i += 256) {
         tw[i] = ((const float2 *) g.twiddle)[i];
         win[i] = g.window[i];
@@ -254,32 +269,24 @@ __global__ __launch_bounds__(256) void analysis_kernel(AnalysisArgs g) {
     __syncthreads();
 
     float *buf = fftbuf + wave * kFftBufFloats;
-    const size_t row_len = (size_t) g.T * kFrame;
 
+#pragma unroll
     for (int f = 0; f < 4; ++f) {
         const int row = wave * 4 + f;
         const int b = mt * 16 + row;
-        const bool valid = b < g.B;
-        // lane handles z[n] = x[2n] + i x[2n+1], n = lane + 64 r; r = 0,1 -> history, r = 2,3 -> new frame
-        const int16_t *cur = g.pcm + (size_t) b * row_len + (size_t) t * kFrame;
-        const int16_t *old = (t == 0) ? g.hist_in + (size_t) b * kFrame : cur - kFrame;
         cpx v[4];
-        int raw[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = lane + 64 * r;
-            const int16_t *src = (r < 2) ? old + 2 * n : cur + 2 * (n - 128);
-            int pr = 0;
-            if (valid) pr = *(const int *) src;
-            raw[r] = pr;
+            const int pr = raw[f][r];
             float lo = (float) (int16_t) (pr & 0xffff), hi = (float) (int16_t) (pr >> 16);
             v[r].x = (lo * (1.0f / 32768.0f)) * win[2 * n];
             v[r].y = (hi * (1.0f / 32768.0f)) * win[2 * n + 1];
         }
         if (t == g.T - 1 && b < g.Bpad) {
             int *h = (int *) (g.hist_out + (size_t) b * kFrame);
-            h[lane] = raw[2];
-            h[lane + 64] = raw[3];
+            h[lane] = raw[f][2];
+            h[lane + 64] = raw[f][3];
         }
         fft256_wave(v, buf, tw, lane);
         float2 *spec = (float2 *) g.spec + ((size_t) t * g.Bpad + b) * 256;
@@ -363,33 +370,69 @@ __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
         tl[f][1] = tp[lane + 64];
     }
 
-    for (int t = (t0 > 0 ? t0 - 1 : 0); t < t1; ++t) {
+    // software pipeline: the mask tile of frame t+1 and the spectrum of the next (frame, stream) are requested from HBM
+    // before the current one is transformed; without it every wave sits out one memory latency per frame
+    const int tb = (t0 > 0 ? t0 - 1 : 0);
+    constexpr int kMaskVecs = (kMaskTiles * 64 + 255) / 256;  // f32x4 per thread per mask tile
+    f32x4 mnext[kMaskVecs];
+    auto mask_fetch = [&](int t) {
+        const f32x4 *src = (const f32x4 *) g.mask + ((size_t) t * mtiles + mt) * kMaskTiles * 64;
+#pragma unroll
+        for (int j = 0; j < kMaskVecs; ++j) {
+            const int i = tid + 256 * j;
+            if (i < kMaskTiles * 64) mnext[j] = src[i];
+        }
+    };
+    float2 sk[4], sc[4];
+    auto spec_fetch = [&](int t, int f) {
+        const int b = mt * 16 + wave * 4 + f;
+        const float2 *spec = (const float2 *) g.spec + ((size_t) t * g.Bpad + b) * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = lane + 64 * r;
+            sk[r] = spec[k];
+            sc[r] = spec[(256 - k) & 255];
+        }
+    };
+    mask_fetch(tb);
+    spec_fetch(tb, 0);
+
+    for (int t = tb; t < t1; ++t) {
         const bool emit = t >= t0;
         __syncthreads();  // previous frame's readers are done with the mask tile
-        {
-            // C-packed fp32 tile [17][64 lanes][4 rows] -> row-major [16][kMaskLd]
-            const f32x4 *src = (const f32x4 *) g.mask + ((size_t) t * mtiles + mt) * kMaskTiles * 64;
-            for (int i = tid; i < kMaskTiles * 64; i += 256) {
-                const f32x4 v = src[i];
+        // C-packed fp32 tile [17][64 lanes][4 rows] -> row-major [16][kMaskLd]
+#pragma unroll
+        for (int j = 0; j < kMaskVecs; ++j) {
+            const int i = tid + 256 * j;
+            if (i < kMaskTiles * 64) {
                 const int nt = i >> 6, l = i & 63;
                 const int col = nt * 16 + (l & 15), row = (l >> 4) * 4;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mrow[(row + r) * kMaskLd + col] = v[r];
+                for (int r = 0; r < 4; ++r) mrow[(row + r) * kMaskLd + col] = mnext[j][r];
             }
         }
+        if (t + 1 < t1) mask_fetch(t + 1);
         __syncthreads();
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             const int row = wave * 4 + f;
             const int b = mt * 16 + row;
-            const float2 *spec = (const float2 *) g.spec + ((size_t) t * g.Bpad + b) * 256;
             const float *mk_row = mrow + row * kMaskLd;
+            float2 ck[4], cc[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ck[r] = sk[r];
+                cc[r] = sc[r];
+            }
+            if (f < 3)
+                spec_fetch(t, f + 1);
+            else if (t + 1 < t1)
+                spec_fetch(t + 1, 0);
             cpx v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = lane + 64 * r;
-                const int kc = (256 - k) & 255;
-                float2 xk = spec[k], xc = spec[kc];
+                float2 xk = ck[r], xc = cc[r];
                 float mk = mk_row[k];
                 float mc = mk_row[256 - k];  // mirrored bin (256 when k == 0)
                 cpx yk, yc;
