@@ -142,14 +142,7 @@ struct PBF16 {
     }
     static __device__ __forceinline__ int off(int rc, int kk) { return pack_off_bf16(rc, kk); }
     static __device__ __forceinline__ elem_t cvt(float v) { return f2bf(v); }
-    static __device__ __forceinline__ gi_t to_gi(f32x4 v) {
-        gi_t r;
-        r[0] = (_Float16) v[0];
-        r[1] = (_Float16) v[1];
-        r[2] = (_Float16) v[2];
-        r[3] = (_Float16) v[3];
-        return r;
-    }
+    static __device__ __forceinline__ gi_t to_gi(f32x4 v) { return __builtin_convertvector(v, gi_t); }
     static __device__ __forceinline__ f32x4 from_gi(gi_t v) {
         f32x4 r;
         r[0] = (float) v[0];
@@ -792,6 +785,137 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_kernel(GemmArgs g) {
     }
 }
 
+// ---- second form of the weight-stationary input GEMM: the 51 n-tiles are split over a PAIR of workgroups that sit on
+// the same XCD (blocks g and g + 8), so one wave keeps at most 7 n-tiles x (9 + NB0) k-blocks = 77 fragments -- all of
+// them in registers (3 n-tiles in VGPRs, 4 pinned in AGPRs), including the y_prev part.  No weight ever comes from LDS
+// or L2 inside the loop; LDS only double-buffers A tiles, kWs2Stage m-tiles per barrier.  The partner's second read of
+// an A tile hits the XCD's L2.
+constexpr int kWs2Stage = 2;    // m-tiles staged per barrier
+constexpr int kWs2Tiles = 7;    // n-tiles per wave (the 7th only on some waves)
+
+template <int NB0>
+__global__ __launch_bounds__(256, 1) void gemm_ws2_kernel(GemmArgs g) {
+    typedef PBF16 P;
+    typedef P::frag_t frag_t;
+    constexpr int NB = P::NBH + NB0;
+    __shared__ __attribute__((aligned(16))) char smem[2 * kWs2Stage * NB * 1024];
+    frag_t *abuf = (frag_t *) smem;  // [2][kWs2Stage][NB][64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int colq = lane & 15;
+    const int bid = blockIdx.x;
+    const int half = (bid >> 3) & 1;
+    const int mgroup = (bid >> 4) * 8 + (bid & 7);      // 0 .. gridDim.x / 2 - 1
+    const int mstride = (gridDim.x >> 1) * kWs2Stage;   // m-tiles between consecutive stages of this workgroup
+    const int nt_base = half ? 26 : 0, nt_count = half ? kGateTiles - 26 : 26;
+    const frag_t *w = (const frag_t *) g.w;
+
+    // this wave's n-tiles: nt_base + wave + 4 j; j < 6 always exists, j = 6 only on the first waves of a half
+    int nt[kWs2Tiles];
+#pragma unroll
+    for (int j = 0; j < kWs2Tiles; ++j) nt[j] = nt_base + (wave + 4 * j < nt_count ? wave + 4 * j : 0);
+    const bool has7 = wave + 24 < nt_count;
+    frag_t wv[3][NB], wa[4][NB];
+    float bias[kWs2Tiles];
+#pragma unroll
+    for (int j = 0; j < kWs2Tiles; ++j) {
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+            frag_t x = w[((size_t) nt[j] * NB + blk) * 64 + lane];
+            if (j < 3)
+                wv[j < 3 ? j : 0][blk] = x;
+            else
+                wa[j >= 3 ? j - 3 : 0][blk] = pin_to_agpr(x);
+        }
+        bias[j] = g.bias[nt[j] * 16 + colq];
+    }
+
+    // A staging: block i of a stage (i = m * NB + blk; blk < NB0 is the y part) is fetched by wave i & 3.
+    // The launch guarantees mtiles % (kWs2Stage * gridDim.x / 2) == 0, so every staged m-tile exists.
+    constexpr int kStageBlocks = kWs2Stage * NB;
+    constexpr int kFetch = (kStageBlocks + 3) / 4;
+    const frag_t *src[kFetch];
+    size_t step[kFetch];
+#pragma unroll
+    for (int i = 0; i < kFetch; ++i) {
+        const int idx = wave + 4 * i;
+        const int m = idx / NB, blk = idx % NB;
+        const int mt = mgroup * kWs2Stage + m;
+        if (blk < NB0) {
+            src[i] = (const frag_t *) g.a0 + ((size_t) mt * NB0 + blk) * 64 + lane;
+            step[i] = (size_t) mstride * NB0 * 64;
+        } else {
+            src[i] = (const frag_t *) g.a1 + ((size_t) mt * P::NBH + (blk - NB0)) * 64 + lane;
+            step[i] = (size_t) mstride * P::NBH * 64;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kFetch; ++i)
+        if (wave + 4 * i < kStageBlocks) abuf[(wave + 4 * i) * 64 + lane] = *src[i];
+    __syncthreads();
+
+    auto store_tile = [&](P::gi_t *out, int j, f32x4 v) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[j];
+        out[nt[j] * 64 + lane] = P::to_gi(v);
+    };
+
+    int cur = 0;
+    for (int mt0 = mgroup * kWs2Stage; mt0 < g.mtiles; mt0 += mstride) {
+        const bool more = mt0 + mstride < g.mtiles;
+        frag_t stage[kFetch];
+#pragma unroll
+        for (int i = 0; i < kFetch; ++i) {
+            src[i] += step[i];
+            if (more && wave + 4 * i < kStageBlocks) stage[i] = *src[i];  // in flight during this stage's MFMAs
+        }
+#pragma unroll
+        for (int m = 0; m < kWs2Stage; ++m) {
+            const frag_t *ab = abuf + (cur * kStageBlocks + m * NB) * 64;
+            frag_t a[NB];
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) a[blk] = ab[blk * 64 + lane];
+            P::gi_t *out = (P::gi_t *) g.out + (size_t) (mt0 + m) * kGateTiles * 64;
+            // n-tiles {0,1,2} from VGPRs, {3,4,5} from AGPRs: three independent accumulator chains each
+            f32x4 acc[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[c] = P::mma(a[blk], wv[c][blk], acc[c]);
+            f32x4 acc2[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc2[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc2[c] = P::mma(a[blk], wa[c][blk], acc2[c]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) store_tile(out, c, acc[c]);
+            if (m == kWs2Stage - 1) {
+                // hand the next stage's A tiles to LDS here: the only VMEM younger than those loads are the three stores
+                // just issued, so the wait (vmcnt counts stores too on gfx950) is short
+#pragma unroll
+                for (int i = 0; i < kFetch; ++i)
+                    if (more && wave + 4 * i < kStageBlocks)
+                        abuf[((cur ^ 1) * kStageBlocks + wave + 4 * i) * 64 + lane] = stage[i];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) store_tile(out, 3 + c, acc2[c]);
+            if (has7) {
+                f32x4 acc3 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk) acc3 = P::mma(a[blk], wa[3][blk], acc3);
+                store_tile(out, 6, acc3);
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
 template <class P>
 static void launch_gemm_p(const GemmArgs &a, hipStream_t s) {
     const int nb = a.nb0 + a.nb1;
@@ -815,12 +939,22 @@ void launch_gemm(const GemmArgs &a, hipStream_t s) {
     static const bool no_ws = getenv("KOALA_AMD_GEMM_GENERIC") != nullptr;  // A/B switch for profiling
     if (a.precision == kBf16 && a.out_kind == kOutGi && a.ntiles == kGateTiles && a.nb1 == PBF16::NBH && a.nb0 <= 2 &&
         a.mtiles >= 256 && !no_ws) {
-        if (a.nb0 == 0)
-            hipLaunchKernelGGL(gemm_ws_kernel<0>, dim3(256), dim3(256), 0, s, a);
-        else if (a.nb0 == 1)
-            hipLaunchKernelGGL(gemm_ws_kernel<1>, dim3(256), dim3(256), 0, s, a);
-        else
-            hipLaunchKernelGGL(gemm_ws_kernel<2>, dim3(256), dim3(256), 0, s, a);
+        static const bool ws1 = getenv("KOALA_AMD_GEMM_WS1") != nullptr;  // A/B switch: first weight-stationary form
+        if (ws1 || a.mtiles % (128 * kWs2Stage) != 0) {
+            if (a.nb0 == 0)
+                hipLaunchKernelGGL(gemm_ws_kernel<0>, dim3(256), dim3(256), 0, s, a);
+            else if (a.nb0 == 1)
+                hipLaunchKernelGGL(gemm_ws_kernel<1>, dim3(256), dim3(256), 0, s, a);
+            else
+                hipLaunchKernelGGL(gemm_ws_kernel<2>, dim3(256), dim3(256), 0, s, a);
+        } else {
+            if (a.nb0 == 0)
+                hipLaunchKernelGGL(gemm_ws2_kernel<0>, dim3(256), dim3(256), 0, s, a);
+            else if (a.nb0 == 1)
+                hipLaunchKernelGGL(gemm_ws2_kernel<1>, dim3(256), dim3(256), 0, s, a);
+            else
+                hipLaunchKernelGGL(gemm_ws2_kernel<2>, dim3(256), dim3(256), 0, s, a);
+        }
         return;
     }
     if (a.precision == kBf16)

@@ -24,6 +24,8 @@ buf = (C.c_ulonglong * 64)()
 l.pv_koala_debug_timing(buf)
 t = np.array(buf[:9], dtype=np.int64)
 w = np.array(buf[16:25], dtype=np.int64)
+w2 = np.array(buf[32:41], dtype=np.int64)
+pass
 print('ws gemm:', {n: int(d) for n, d in zip(['stage issue + A read', 'tile0', 'tile1', 'tile2', 'tile3', 'tile4', 'stage write', 'barrier'], np.diff(w))})
 print('stamps (s_memtime ticks rel.):', (t - t[0]).tolist())
 names = ['A frags read', 'tile0', 'tile1', 'tile2', 'tile3', 'tile4', 'pre-barrier', 'barrier']
