@@ -1073,6 +1073,21 @@ __global__ __launch_bounds__(256, P::kGruWaves) void gru_kernel(GruArgs g) {
     }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 fast_sigmoid2(f32x2 x) {
+    f32x2 e = x * f32x2{-1.44269504088896341f, -1.44269504088896341f};
+    e = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + f32x2{1.0f, 1.0f};
+    return f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+}
+__device__ __forceinline__ f32x2 fast_tanh2(f32x2 x) {
+    f32x2 e = x * f32x2{2.88539008177792681f, 2.88539008177792681f};
+    e = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + f32x2{1.0f, 1.0f};
+    f32x2 r = f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+    return f32x2{1.0f, 1.0f} - (r + r);
+}
+
 __global__ __launch_bounds__(256, 1) void gru_resident_kernel(GruArgs g) {
     typedef PBF16 P;
     typedef P::frag_t frag_t;
@@ -1184,15 +1199,24 @@ __global__ __launch_bounds__(256, 1) void gru_resident_kernel(GruArgs g) {
                 const float br = lbias[(u * 3 + 0) * 16 + colq], bz = lbias[(u * 3 + 1) * 16 + colq],
                             bn = lbias[(u * 3 + 2) * 16 + colq];
                 const int k = u * 16 + colq;
-                uint16_t *dst = (uint16_t *) hn + (k / P::KB) * 64 * P::EPL;
+                uint16_t *dst = (uint16_t *) hn + (k / P::KB) * 64 * P::EPL + P::off(rowq, k % P::KB);
+                const f32x2 vbr = {br, br}, vbz = {bz, bz}, vbn = {bn, bn};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float r = fast_sigmoid(ir[i] + (acc[0][i] + br));
-                    float z = fast_sigmoid(iz[i] + (acc[1][i] + bz));
-                    float n = fast_tanh(__builtin_fmaf(r, acc[2][i] + bn, in[i]));
-                    float h = __builtin_fmaf(z, hreg[q][i] - n, n);
-                    hreg[q][i] = h;
-                    dst[P::off(rowq + i, k % P::KB)] = P::cvt(h);
+                for (int p = 0; p < 2; ++p) {
+                    const f32x2 ar = {acc[0][2 * p], acc[0][2 * p + 1]}, az = {acc[1][2 * p], acc[1][2 * p + 1]},
+                                an = {acc[2][2 * p], acc[2][2 * p + 1]};
+                    const f32x2 xr = {ir[2 * p], ir[2 * p + 1]}, xz = {iz[2 * p], iz[2 * p + 1]},
+                                xn = {in[2 * p], in[2 * p + 1]};
+                    const f32x2 r = fast_sigmoid2(xr + (ar + vbr));
+                    const f32x2 z = fast_sigmoid2(xz + (az + vbz));
+                    const f32x2 n = fast_tanh2(r * (an + vbn) + xn);
+                    const f32x2 hp = {hreg[q][2 * p], hreg[q][2 * p + 1]};
+                    const f32x2 h = z * (hp - n) + n;
+                    hreg[q][2 * p] = h[0];
+                    hreg[q][2 * p + 1] = h[1];
+                    const uint32_t bits = __builtin_bit_cast(uint32_t, __builtin_convertvector(h, bf16x2));
+                    dst[(2 * p) * 8] = (uint16_t) bits;  // consecutive rows sit 8 elements apart in an A-packed block
+                    dst[(2 * p + 1) * 8] = (uint16_t) (bits >> 16);
                 }
                 KNS_STAMP(2 + q);
             }
