@@ -8,6 +8,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace kns {
@@ -221,6 +222,7 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
         return false;
     }
     stream_ = own_stream_;
+    use_graph_ = getenv("KOALA_AMD_NO_GRAPH") == nullptr;
 
     // ---- tables
     std::vector<float> win(kNfft), tw(2 * kNfft);
@@ -324,6 +326,7 @@ Engine::~Engine() {
         (void) hipEventDestroy(s.b);
     }
     for (hipEvent_t e : pool_) (void) hipEventDestroy(e);
+    if (frame_graph_) (void) hipGraphExecDestroy(frame_graph_);
     for (void *p : allocs_) (void) hipFree(p);
     if (h_in_) (void) hipHostFree(h_in_);
     if (h_out_) (void) hipHostFree(h_out_);
@@ -428,8 +431,11 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
 
     AnalysisArgs an;
     an.pcm = d_pcm;
+    // T == 1: the one workgroup that reads a stream's history also writes it (same lanes, same addresses), so the state
+    // is updated in place and the launch arguments never change -- which is what lets the frame be a hipGraph
+    const bool in_place = T == 1;
     an.hist_in = d_hist_[hist_cur_];
-    an.hist_out = d_hist_[hist_cur_ ^ 1];
+    an.hist_out = d_hist_[in_place ? hist_cur_ : hist_cur_ ^ 1];
     an.window = d_window_;
     an.twiddle = d_twiddle_;
     an.mean = d_mean_;
@@ -444,7 +450,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     tick(kClsAnalysis);
     launch_analysis(an, stream_);
     tock(kClsAnalysis);
-    hist_cur_ ^= 1;
+    if (!in_place) hist_cur_ ^= 1;
 
     auto gemm = [&](int cls, const void *a0, int nb0, const void *a1, int nb1, const void *w, const float *bias,
                     void *out, int ntiles, int n_valid, int kind) {
@@ -503,7 +509,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     sy.window = d_window_;
     sy.twiddle = d_twiddle_;
     sy.tail_in = d_tail_[tail_cur_];
-    sy.tail_out = d_tail_[tail_cur_ ^ 1];
+    sy.tail_out = d_tail_[in_place ? tail_cur_ : tail_cur_ ^ 1];
     sy.seg = T <= 4 ? T : 4;
     sy.out = d_out;
     sy.B = B_;
@@ -512,7 +518,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     tick(kClsSynthesis);
     launch_synthesis(sy, stream_);
     tock(kClsSynthesis);
-    tail_cur_ ^= 1;
+    if (!in_place) tail_cur_ ^= 1;
 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -541,6 +547,23 @@ bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err) 
     }
     if (dev_in) return run_device(T, pcm, out, err);
     memcpy(h_in_, pcm, bytes);
+    if (T == 1 && use_graph_ && stream_ == own_stream_ && !profiling_) {
+        // frame-by-frame streaming: copy-in, the 23 kernels and copy-out replayed as one hipGraph
+        if (!frame_graph_) {
+            hipGraph_t graph = nullptr;
+            if (hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal) != hipSuccess) goto fail;
+            bool ok = hipMemcpyAsync(d_in_, h_in_, bytes, hipMemcpyHostToDevice, stream_) == hipSuccess;
+            ok = ok && run_device(1, d_in_, d_out_, err);
+            ok = ok && hipMemcpyAsync(h_out_, d_out_, bytes, hipMemcpyDeviceToHost, stream_) == hipSuccess;
+            if (hipStreamEndCapture(stream_, &graph) != hipSuccess || !ok) goto fail;
+            if (hipGraphInstantiate(&frame_graph_, graph, nullptr, nullptr, 0) != hipSuccess) goto fail;
+            (void) hipGraphDestroy(graph);
+        }
+        if (hipGraphLaunch(frame_graph_, stream_) != hipSuccess) goto fail;
+        if (hipStreamSynchronize(stream_) != hipSuccess) goto fail;
+        memcpy(out, h_out_, bytes);
+        return true;
+    }
     if (hipMemcpyAsync(d_in_, h_in_, bytes, hipMemcpyHostToDevice, stream_) != hipSuccess) goto fail;
     if (!run_device(T, d_in_, d_out_, err)) return false;
     if (hipMemcpyAsync(h_out_, d_out_, bytes, hipMemcpyDeviceToHost, stream_) != hipSuccess) goto fail;

@@ -91,6 +91,10 @@ private:
     // staging for host-pointer calls
     int16_t *d_in_ = nullptr, *d_out_ = nullptr, *h_in_ = nullptr, *h_out_ = nullptr;
 
+    // hipGraph of one host-pointer frame (copy-in, 23 kernels, copy-out); built on first use
+    hipGraphExec_t frame_graph_ = nullptr;
+    bool use_graph_ = true;
+
     // profiling
     bool profiling_ = false;
     struct Span {
