@@ -285,7 +285,8 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     d_hist_[1] = (int16_t *) dalloc((size_t) Bpad_ * kFrame * 2, true);
     d_tail_[0] = (float *) dalloc((size_t) Bpad_ * kFrame * 4, true);
     d_tail_[1] = (float *) dalloc((size_t) Bpad_ * kFrame * 4, true);
-    d_hstate_ = (float *) dalloc((size_t) kGruLayers * mtb * kUnitTiles * 1024, true);
+    d_hstate_[0] = (float *) dalloc((size_t) kGruLayers * mtb * kUnitTiles * 1024, true);
+    d_hstate_[1] = (float *) dalloc((size_t) kGruLayers * mtb * kUnitTiles * 1024, true);
     d_rmask_ = (uint8_t *) dalloc((size_t) Bpad_, true);
 
     // ---- activation workspace
@@ -326,7 +327,8 @@ Engine::~Engine() {
         (void) hipEventDestroy(s.b);
     }
     for (hipEvent_t e : pool_) (void) hipEventDestroy(e);
-    if (frame_graph_) (void) hipGraphExecDestroy(frame_graph_);
+    for (hipGraphExec_t ge : frame_graph_)
+        if (ge) (void) hipGraphExecDestroy(ge);
     for (void *p : allocs_) (void) hipFree(p);
     if (h_in_) (void) hipHostFree(h_in_);
     if (h_out_) (void) hipHostFree(h_out_);
@@ -405,7 +407,8 @@ bool Engine::reset(const uint8_t *host_mask, std::string *err) {
     r.hist2 = d_hist_[1];
     r.tail = d_tail_[0];
     r.tail2 = d_tail_[1];
-    r.hstate = d_hstate_;
+    r.hstate = d_hstate_[0];
+    r.hstate2 = d_hstate_[1];
     r.Bpad = Bpad_;
     r.mask = nullptr;
     if (host_mask) {
@@ -476,7 +479,8 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         g.gi = d_gi_;
         g.whh = whh;
         g.bhh = bhh;
-        g.hstate = d_hstate_ + (size_t) layer * mtb * kUnitTiles * 256;
+        g.hstate_in = d_hstate_[hs_cur_] + (size_t) layer * mtb * kUnitTiles * 256;
+        g.hstate_out = d_hstate_[hs_cur_ ^ 1] + (size_t) layer * mtb * kUnitTiles * 256;
         g.hseq = hseq;
         g.T = T;
         g.mtiles = mtb;
@@ -486,16 +490,43 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         tock(kClsGru);
     };
 
+    // one frame of a few m-tiles: latency matters, not throughput -- whole GRU layers as single wide launches
+    const bool small = T == 1 && mtb <= 16 && getenv("KOALA_AMD_NO_SMALL") == nullptr;
+    auto gru_small = [&](const void *a0, int nb0, const void *a1, const void *wih, const float *bih, const void *whh,
+                         const float *bhh, int layer, void *hseq) {
+        GruSmallArgs g;
+        g.a0 = a0;
+        g.a1 = a1;
+        g.wih = wih;
+        g.bih = bih;
+        g.whh = whh;
+        g.bhh = bhh;
+        g.hstate_in = d_hstate_[hs_cur_] + (size_t) layer * mtb * kUnitTiles * 256;
+        g.hstate_out = d_hstate_[hs_cur_ ^ 1] + (size_t) layer * mtb * kUnitTiles * 256;
+        g.hseq = hseq;
+        g.nb0 = nb0;
+        g.mtiles = mtb;
+        g.precision = prec_;
+        tick(kClsGru);
+        launch_gru_small(g, stream_);
+        tock(kClsGru);
+    };
+
     // front-end: e = features . W_in + b_in
     gemm(kClsGemmHead, nullptr, 0, d_feat_, nbf_, w_in_, b_in_, d_e_, nbh_ * pi_.npb, kHidden, kOutAPlain);
     for (int s = 0; s < kStages; ++s) {
         const StageDev &d = sd_[s];
         const void *yprev = s ? d_y_[s - 1] : nullptr;
         const int nby = s ? nby_[s - 1] : 0;
-        gemm(kClsGemmIn, yprev, nby, d_e_, nbh_, d.w_ih_a, d.b_ih_a, d_gi_, kGateTiles, 3 * kHidden, kOutGi);
-        gru(d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_);
-        gemm(kClsGemmIn, nullptr, 0, d_hseq_a_, nbh_, d.w_ih_b, d.b_ih_b, d_gi_, kGateTiles, 3 * kHidden, kOutGi);
-        gru(d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_);
+        if (small) {
+            gru_small(yprev, nby, d_e_, d.w_ih_a, d.b_ih_a, d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_);
+            gru_small(nullptr, 0, d_hseq_a_, d.w_ih_b, d.b_ih_b, d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_);
+        } else {
+            gemm(kClsGemmIn, yprev, nby, d_e_, nbh_, d.w_ih_a, d.b_ih_a, d_gi_, kGateTiles, 3 * kHidden, kOutGi);
+            gru(d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_);
+            gemm(kClsGemmIn, nullptr, 0, d_hseq_a_, nbh_, d.w_ih_b, d.b_ih_b, d_gi_, kGateTiles, 3 * kHidden, kOutGi);
+            gru(d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_);
+        }
         if (s < kStages - 1)
             gemm(kClsGemmHead, nullptr, 0, d_hseq_b_, nbh_, d.w_head, d.b_head, d_y_[s], d.head_tiles, d.head_dim,
                  kOutASigmoid);
@@ -518,6 +549,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     tick(kClsSynthesis);
     launch_synthesis(sy, stream_);
     tock(kClsSynthesis);
+    hs_cur_ ^= 1;
     if (!in_place) tail_cur_ ^= 1;
 
     hipError_t e = hipGetLastError();
@@ -549,17 +581,20 @@ bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err) 
     memcpy(h_in_, pcm, bytes);
     if (T == 1 && use_graph_ && stream_ == own_stream_ && !profiling_) {
         // frame-by-frame streaming: copy-in, the 23 kernels and copy-out replayed as one hipGraph
-        if (!frame_graph_) {
+        const int parity = hs_cur_;
+        if (!frame_graph_[parity]) {
             hipGraph_t graph = nullptr;
             if (hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal) != hipSuccess) goto fail;
             bool ok = hipMemcpyAsync(d_in_, h_in_, bytes, hipMemcpyHostToDevice, stream_) == hipSuccess;
             ok = ok && run_device(1, d_in_, d_out_, err);
             ok = ok && hipMemcpyAsync(h_out_, d_out_, bytes, hipMemcpyDeviceToHost, stream_) == hipSuccess;
             if (hipStreamEndCapture(stream_, &graph) != hipSuccess || !ok) goto fail;
-            if (hipGraphInstantiate(&frame_graph_, graph, nullptr, nullptr, 0) != hipSuccess) goto fail;
+            if (hipGraphInstantiate(&frame_graph_[parity], graph, nullptr, nullptr, 0) != hipSuccess) goto fail;
             (void) hipGraphDestroy(graph);
+            hs_cur_ = parity;  // the capture only recorded the launches; run_device's bookkeeping is replayed below
         }
-        if (hipGraphLaunch(frame_graph_, stream_) != hipSuccess) goto fail;
+        if (hipGraphLaunch(frame_graph_[parity], stream_) != hipSuccess) goto fail;
+        hs_cur_ = parity ^ 1;
         if (hipStreamSynchronize(stream_) != hipSuccess) goto fail;
         memcpy(out, h_out_, bytes);
         return true;
@@ -646,7 +681,7 @@ int64_t Engine::debug_read(int what, float *out, int64_t capacity, std::string *
     } else if (what == 3) {  // hidden state
         n = (int64_t) kGruLayers * B_ * kHidden;
         if (n > capacity) return -2;
-        auto h = fetch(d_hstate_, (size_t) kGruLayers * mtb * kUnitTiles * 1024);
+        auto h = fetch(d_hstate_[hs_cur_], (size_t) kGruLayers * mtb * kUnitTiles * 1024);
         const float *s = (const float *) h.data();
         for (int l = 0; l < kGruLayers; ++l)
             for (int b = 0; b < B_; ++b)

@@ -79,8 +79,8 @@ private:
     // per-stream state
     int16_t *d_hist_[2] = {nullptr, nullptr};
     int hist_cur_ = 0;
-    float *d_tail_[2] = {nullptr, nullptr}, *d_hstate_ = nullptr;
-    int tail_cur_ = 0;
+    float *d_tail_[2] = {nullptr, nullptr}, *d_hstate_[2] = {nullptr, nullptr};
+    int tail_cur_ = 0, hs_cur_ = 0;
     uint8_t *d_rmask_ = nullptr;
 
     // activation workspace (fragment layouts)
@@ -92,7 +92,7 @@ private:
     int16_t *d_in_ = nullptr, *d_out_ = nullptr, *h_in_ = nullptr, *h_out_ = nullptr;
 
     // hipGraph of one host-pointer frame (copy-in, 23 kernels, copy-out); built on first use
-    hipGraphExec_t frame_graph_ = nullptr;
+    hipGraphExec_t frame_graph_[2] = {nullptr, nullptr};  // one per parity of the hidden-state ping-pong
     bool use_graph_ = true;
 
     // profiling

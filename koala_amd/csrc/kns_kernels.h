@@ -62,11 +62,29 @@ struct GruArgs {
     const void *gi;     // C-packed [T][mtiles][51] tiles of (x . W_ih + b_ih)
     const void *whh;    // B-packed [51][nbh] blocks
     const float *bhh;   // [51 * 16]
-    float *hstate;      // C-packed fp32 [mtiles][17][64][4], in/out
+    const float *hstate_in;  // C-packed fp32 [mtiles][17][64][4]: hidden state before this call
+    float *hstate_out;       // the same after this call (ping-pong with hstate_in: the small-batch kernel reads whole
+                             // state tiles in every workgroup, so it may not be updated in place)
     void *hseq;         // A-packed [T][mtiles][nbh] blocks, out
     int T, mtiles, precision;
 };
 void launch_gru(const GruArgs &a, hipStream_t s);
+
+// ---- a whole GRU layer (input GEMM + recurrent step + gates) for ONE frame of a few m-tiles: the low-latency path.
+// One wavefront per (unit tile, m-tile): 17 x mtiles workgroups each stream only their 3 n-tiles of W_ih and W_hh.
+struct GruSmallArgs {
+    const void *a0;     // A-packed y_prev [mtiles][nb0] (null when nb0 == 0)
+    const void *a1;     // A-packed e or previous layer's h [mtiles][nbh]
+    const void *wih;    // B-packed [51][nb0 + nbh]
+    const float *bih;   // [51 * 16]
+    const void *whh;    // B-packed [51][nbh]
+    const float *bhh;   // [51 * 16]
+    const float *hstate_in;
+    float *hstate_out;
+    void *hseq;         // A-packed [mtiles][nbh], out (this frame's h as the next kernel's A operand)
+    int nb0, mtiles, precision;
+};
+void launch_gru_small(const GruSmallArgs &a, hipStream_t s);
 
 // ---- state reset of selected streams
 struct ResetArgs {
@@ -74,7 +92,8 @@ struct ResetArgs {
     int16_t *hist2;
     float *tail;     // [Bpad][256] (both ping-pong copies are cleared)
     float *tail2;
-    float *hstate;   // [8][mtiles][17][64][4]
+    float *hstate;   // [8][mtiles][17][64][4] (both ping-pong copies are cleared)
+    float *hstate2;
     const uint8_t *mask;  // [Bpad] device copy, or null for all
     int Bpad;
 };

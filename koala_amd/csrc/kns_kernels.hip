@@ -982,7 +982,7 @@ __global__ __launch_bounds__(256, P::kGruWaves) void gru_kernel(GruArgs g) {
     for (int q = 0; q < kGruTilesPerWave; ++q) {
         const int u = wave + 4 * q;
         hreg[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (u < kUnitTiles) hreg[q] = ((const f32x4 *) g.hstate)[((size_t) mt * kUnitTiles + u) * 64 + lane];
+        if (u < kUnitTiles) hreg[q] = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u) * 64 + lane];
     }
     for (int i = tid; i < 2 * NBH * 64; i += 256) ((uint4 *) hbuf)[i] = uint4{0, 0, 0, 0};
     __syncthreads();
@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(256, P::kGruWaves) void gru_kernel(GruArgs g) {
 #pragma unroll
     for (int q = 0; q < kGruTilesPerWave; ++q) {
         const int u = wave + 4 * q;
-        if (u < kUnitTiles) ((f32x4 *) g.hstate)[((size_t) mt * kUnitTiles + u) * 64 + lane] = hreg[q];
+        if (u < kUnitTiles) ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u) * 64 + lane] = hreg[q];
     }
 }
 
@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(256, 1) void gru_resident_kernel(GruArgs g) {
     for (int q = 0; q < kGruTilesPerWave; ++q) {
         const int u = wave + 4 * q;
         hreg[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (u < kUnitTiles) hreg[q] = ((const f32x4 *) g.hstate)[((size_t) mt * kUnitTiles + u) * 64 + lane];
+        if (u < kUnitTiles) hreg[q] = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u) * 64 + lane];
     }
     for (int i = tid; i < 2 * NBH * 64; i += 256) ((uint4 *) smem)[i] = uint4{0, 0, 0, 0};
     __syncthreads();
@@ -1233,8 +1233,106 @@ __global__ __launch_bounds__(256, 1) void gru_resident_kernel(GruArgs g) {
 #pragma unroll
     for (int q = 0; q < kGruTilesPerWave; ++q) {
         const int u = wave + 4 * q;
-        if (u < kUnitTiles) ((f32x4 *) g.hstate)[((size_t) mt * kUnitTiles + u) * 64 + lane] = hreg[q];
+        if (u < kUnitTiles) ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u) * 64 + lane] = hreg[q];
     }
+}
+
+// ---- low-latency GRU layer: input GEMM + recurrent GEMM + gates of one frame, one wavefront per (unit tile, m-tile).
+// Arithmetic is, operation for operation, what the chunked path does (same MFMA, same k order, gi rounded to its storage
+// type before the gates, same gate formulas per precision), so a stream's samples do not depend on which path ran.
+template <class P>
+__global__ __launch_bounds__(64) void gru_small_kernel(GruSmallArgs g) {
+    typedef typename P::frag_t frag_t;
+    typedef typename P::elem_t elem_t;
+    constexpr int NBH = P::NBH;
+    __shared__ __attribute__((aligned(16))) char hbuf[NBH * 1024];
+    const int lane = threadIdx.x;
+    const int u = blockIdx.x, mt = blockIdx.y;
+    const int colq = lane & 15, rowq = (lane >> 4) * 4;
+    const int nb = g.nb0 + NBH;
+
+    // h_{t-1}: fp32 C-fragments -> operand-typed A-fragments through LDS
+    for (int i = lane; i < NBH * 64; i += 64) ((uint4 *) hbuf)[i] = uint4{0, 0, 0, 0};
+    wave_lds_sync();
+    f32x4 hown = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int v = 0; v < kUnitTiles; ++v) {
+        const f32x4 hv = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + v) * 64 + lane];
+        if (v == u) hown = hv;
+        const int k = v * 16 + colq;
+        elem_t *dst = (elem_t *) hbuf + (k / P::KB) * 64 * P::EPL;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[P::off(rowq + i, k % P::KB)] = P::cvt(hv[i]);
+    }
+    wave_lds_sync();
+
+    const frag_t *wih = (const frag_t *) g.wih, *whh = (const frag_t *) g.whh;
+    f32x4 acci[3], acch[3];
+#pragma unroll
+    for (int gt = 0; gt < 3; ++gt) acci[gt] = acch[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int blk = 0; blk < nb; ++blk) {
+        const frag_t a = blk < g.nb0 ? ((const frag_t *) g.a0)[((size_t) mt * g.nb0 + blk) * 64 + lane]
+                                     : ((const frag_t *) g.a1)[((size_t) mt * NBH + (blk - g.nb0)) * 64 + lane];
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt)
+            acci[gt] = P::mma(a, wih[((size_t) (u * 3 + gt) * nb + blk) * 64 + lane], acci[gt]);
+    }
+#pragma unroll
+    for (int blk = 0; blk < NBH; ++blk) {
+        const frag_t a = ((const frag_t *) hbuf)[blk * 64 + lane];
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt)
+            acch[gt] = P::mma(a, whh[((size_t) (u * 3 + gt) * NBH + blk) * 64 + lane], acch[gt]);
+    }
+    f32x4 gin[3];
+#pragma unroll
+    for (int gt = 0; gt < 3; ++gt) {
+        const float b = g.bih[(u * 3 + gt) * 16 + colq];
+        f32x4 v = acci[gt];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = v[i] + b;
+        gin[gt] = P::from_gi(P::to_gi(v));
+    }
+    const float br = g.bhh[(u * 3 + 0) * 16 + colq], bz = g.bhh[(u * 3 + 1) * 16 + colq],
+                bn = g.bhh[(u * 3 + 2) * 16 + colq];
+    f32x4 hnew;
+    if (P::kPrec == kBf16) {
+        const f32x2 vbr = {br, br}, vbz = {bz, bz}, vbn = {bn, bn};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const f32x2 ar = {acch[0][2 * p], acch[0][2 * p + 1]}, az = {acch[1][2 * p], acch[1][2 * p + 1]},
+                        an = {acch[2][2 * p], acch[2][2 * p + 1]};
+            const f32x2 xr = {gin[0][2 * p], gin[0][2 * p + 1]}, xz = {gin[1][2 * p], gin[1][2 * p + 1]},
+                        xn = {gin[2][2 * p], gin[2][2 * p + 1]};
+            const f32x2 r = fast_sigmoid2(xr + (ar + vbr));
+            const f32x2 z = fast_sigmoid2(xz + (az + vbz));
+            const f32x2 n = fast_tanh2(r * (an + vbn) + xn);
+            const f32x2 hp = {hown[2 * p], hown[2 * p + 1]};
+            const f32x2 h = z * (hp - n) + n;
+            hnew[2 * p] = h[0];
+            hnew[2 * p + 1] = h[1];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float r = kns_sigmoid(gin[0][i] + (acch[0][i] + br));
+            float z = kns_sigmoid(gin[1][i] + (acch[1][i] + bz));
+            float n = kns_tanh(__builtin_fmaf(r, acch[2][i] + bn, gin[2][i]));
+            hnew[i] = __builtin_fmaf(z, hown[i] - n, n);
+        }
+    }
+    ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u) * 64 + lane] = hnew;
+    const int k = u * 16 + colq;
+    elem_t *hs = (elem_t *) g.hseq + ((size_t) mt * NBH + k / P::KB) * 64 * P::EPL;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hs[P::off(rowq + i, k % P::KB)] = P::cvt(hnew[i]);
+}
+
+void launch_gru_small(const GruSmallArgs &a, hipStream_t s) {
+    dim3 grid(kUnitTiles, a.mtiles);
+    if (a.precision == kBf16)
+        hipLaunchKernelGGL(gru_small_kernel<PBF16>, grid, dim3(64), 0, s, a);
+    else
+        hipLaunchKernelGGL(gru_small_kernel<PF32>, grid, dim3(64), 0, s, a);
 }
 
 void launch_gru(const GruArgs &a, hipStream_t s) {
@@ -1260,7 +1358,9 @@ __global__ void reset_kernel(ResetArgs g) {
     const int mtiles = g.Bpad >> 4, mt = b >> 4, row = b & 15;
     for (int i = tid; i < kGruLayers * kUnitTiles * 16; i += 256) {
         const int col = i & 15, u = (i >> 4) % kUnitTiles, layer = (i >> 4) / kUnitTiles;
-        g.hstate[(((size_t) layer * mtiles + mt) * kUnitTiles + u) * 256 + cpack_off(row, col)] = 0.0f;
+        const size_t idx = (((size_t) layer * mtiles + mt) * kUnitTiles + u) * 256 + cpack_off(row, col);
+        g.hstate[idx] = 0.0f;
+        g.hstate2[idx] = 0.0f;
     }
 }
 
