@@ -129,3 +129,30 @@ def test_file_demo_loop_with_delay_compensation(gate_model, test_pcm):
     b = np.array(test_pcm[8960:80000], np.float64)
     assert abs(np.sqrt(np.mean(a * a)) / np.sqrt(np.mean(b * b)) - 1.0) < 0.15
     assert np.corrcoef(a, b)[0, 1] > 0.9
+
+
+def test_file_demo_cli_single_and_batch(gate_model, tmp_path):
+    """koala_amd.demo.koala_demo_file: the reference file demo (and its C test, demo/c/test/test_koala_c.py:56-84:
+    exits 0, prints "Real time factor") plus the many-files mode; both modes must write the same samples."""
+    import subprocess
+    import sys
+    import wave
+    from conftest import GOLDEN, ROOT
+    env = dict(__import__('os').environ, PYTHONPATH=ROOT)
+    single = tmp_path / 'single.wav'
+    r = subprocess.run([sys.executable, '-m', 'koala_amd.demo.koala_demo_file', '--input_path',
+                        GOLDEN + '/test.wav', '--output_path', str(single), '--model_path', gate_model],
+                       capture_output=True, text=True, env=env, cwd=ROOT)
+    assert r.returncode == 0 and 'Real time factor' in r.stdout, r.stderr
+    outdir = tmp_path / 'many'
+    r = subprocess.run([sys.executable, '-m', 'koala_amd.demo.koala_demo_file', '--input_path',
+                        GOLDEN + '/test.wav', GOLDEN + '/noise.wav', '--output_dir', str(outdir), '--model_path',
+                        gate_model, '--frames_per_call', '16'], capture_output=True, text=True, env=env, cwd=ROOT)
+    assert r.returncode == 0 and 'Real time factor' in r.stdout, r.stderr
+
+    def samples(p):
+        with wave.open(str(p)) as w:
+            return np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+    a, b = samples(single), samples(outdir / 'test.wav')
+    assert len(a) == len(b) == 93680 and np.array_equal(a, b)
+    assert frame_rms(samples(outdir / 'noise.wav')) < 0.01
