@@ -916,6 +916,123 @@ __global__ __launch_bounds__(256, 1) void gemm_ws2_kernel(GemmArgs g) {
     }
 }
 
+// ---- weight-stationary form of the narrow GEMMs (front-end 257->271, heads 271->{1,5,40,257}; bf16): 8 waves per
+// workgroup, every wave keeps its n-tiles' 9 k-blocks in VGPRs (at most 36 fragments), a persistent workgroup walks
+// m-tiles with the A tile double-buffered in LDS.  These GEMMs are bound by streaming A in and the result out.
+constexpr int kWsrStage = 2;
+
+template <int OUT, int UW>  // UW: units (pairs of n-tiles for A-packed outputs, single n-tiles for the mask) per wave
+__global__ __launch_bounds__(512, 2) void gemm_wsr_kernel(GemmArgs g) {
+    typedef PBF16 P;
+    typedef P::frag_t frag_t;
+    constexpr int NB = P::NBH;  // both the feature tile (257 -> 288) and a hidden tile (271 -> 288) are 9 k-blocks
+    constexpr bool kApack = (OUT == kOutAPlain || OUT == kOutASigmoid);
+    constexpr bool kSigmoid = (OUT == kOutMask || OUT == kOutASigmoid);
+    constexpr int NU = kApack ? P::NPB : 1;
+    __shared__ __attribute__((aligned(16))) char smem[2 * kWsrStage * NB * 1024 + 8 * 1024];
+    frag_t *abuf = (frag_t *) smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char *scratch = smem + 2 * kWsrStage * NB * 1024 + wave * 1024;  // per-wave transposer for A-packed outputs
+    const int colq = lane & 15;
+    const int units = g.ntiles / NU;
+    const frag_t *w = (const frag_t *) g.w;
+
+    int unit[UW];
+    bool live[UW];
+    frag_t wr[UW * NU][NB];
+    float bias[UW * NU];
+#pragma unroll
+    for (int q = 0; q < UW; ++q) {
+        live[q] = wave + 8 * q < units;
+        unit[q] = live[q] ? wave + 8 * q : 0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            const int nt = unit[q] * NU + j;
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) wr[q * NU + j][blk] = w[((size_t) nt * NB + blk) * 64 + lane];
+            bias[q * NU + j] = g.bias[nt * 16 + colq];
+        }
+    }
+
+    constexpr int kStageBlocks = kWsrStage * NB;
+    constexpr int kFetch = (kStageBlocks + 7) / 8;
+    const int mstride = gridDim.x * kWsrStage;
+    const frag_t *a1p = (const frag_t *) g.a1;
+    int mt0 = blockIdx.x * kWsrStage;
+    for (int i = wave; i < kStageBlocks; i += 8)
+        if (mt0 + i / NB < g.mtiles) abuf[i * 64 + lane] = a1p[((size_t) mt0 * NB + i) * 64 + lane];
+    __syncthreads();
+
+    int cur = 0;
+    for (; mt0 < g.mtiles; mt0 += mstride) {
+        const int mn = mt0 + mstride;
+        frag_t stage[kFetch];
+#pragma unroll
+        for (int i = 0; i < kFetch; ++i) {
+            const int idx = wave + 8 * i;
+            if (idx < kStageBlocks && mn + idx / NB < g.mtiles) stage[i] = a1p[((size_t) mn * NB + idx) * 64 + lane];
+        }
+        if (live[0]) {
+#pragma unroll
+            for (int m = 0; m < kWsrStage; ++m) {
+                const int mt = mt0 + m;
+                if (mt < g.mtiles) {
+                    const frag_t *ab = abuf + (cur * kStageBlocks + m * NB) * 64;
+                    frag_t a[NB];
+#pragma unroll
+                    for (int blk = 0; blk < NB; ++blk) a[blk] = ab[blk * 64 + lane];
+#pragma unroll
+                    for (int q = 0; q < UW; ++q) {
+                        if (live[q]) {
+                            f32x4 acc[NU];
+#pragma unroll
+                            for (int j = 0; j < NU; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+                                for (int j = 0; j < NU; ++j) acc[j] = P::mma(a[blk], wr[q * NU + j][blk], acc[j]);
+#pragma unroll
+                            for (int j = 0; j < NU; ++j) {
+                                const int nt = unit[q] * NU + j;
+                                f32x4 v = acc[j];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    float x = v[i] + bias[q * NU + j];
+                                    if (kSigmoid) x = kns_sigmoid(x);
+                                    if (kApack && nt * 16 + colq >= g.n_valid) x = 0.0f;
+                                    v[i] = x;
+                                }
+                                if (!kApack) {
+                                    ((f32x4 *) g.out)[((size_t) mt * g.ntiles + nt) * 64 + lane] = v;
+                                } else {
+                                    uint16_t *sc = (uint16_t *) scratch;
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i)
+                                        sc[P::off((lane >> 4) * 4 + i, j * 16 + colq)] = P::cvt(v[i]);
+                                }
+                            }
+                            if (kApack) {
+                                wave_lds_sync();
+                                ((uint4 *) g.out)[((size_t) mt * units + unit[q]) * 64 + lane] = ((const uint4 *) scratch)[lane];
+                                wave_lds_sync();
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        frag_t *an = abuf + (cur ^ 1) * kStageBlocks * 64;
+#pragma unroll
+        for (int i = 0; i < kFetch; ++i) {
+            const int idx = wave + 8 * i;
+            if (idx < kStageBlocks && mn + idx / NB < g.mtiles) an[idx * 64 + lane] = stage[i];
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
 template <class P>
 static void launch_gemm_p(const GemmArgs &a, hipStream_t s) {
     const int nb = a.nb0 + a.nb1;
@@ -956,6 +1073,22 @@ void launch_gemm(const GemmArgs &a, hipStream_t s) {
                 hipLaunchKernelGGL(gemm_ws2_kernel<2>, dim3(256), dim3(256), 0, s, a);
         }
         return;
+    }
+    static const bool no_wsr = getenv("KOALA_AMD_GEMM_NO_WSR") != nullptr;  // A/B switch
+    if (a.precision == kBf16 && a.nb0 == 0 && a.nb1 == PBF16::NBH && a.mtiles >= 512 && !no_wsr) {
+        const dim3 grid(256), block(512);
+        if (a.out_kind == kOutAPlain && a.ntiles <= 32) {
+            hipLaunchKernelGGL((gemm_wsr_kernel<kOutAPlain, 2>), grid, block, 0, s, a);
+            return;
+        }
+        if (a.out_kind == kOutASigmoid && a.ntiles <= 16) {
+            hipLaunchKernelGGL((gemm_wsr_kernel<kOutASigmoid, 1>), grid, block, 0, s, a);
+            return;
+        }
+        if (a.out_kind == kOutMask && a.ntiles <= 24) {
+            hipLaunchKernelGGL((gemm_wsr_kernel<kOutMask, 3>), grid, block, 0, s, a);
+            return;
+        }
     }
     if (a.precision == kBf16)
         launch_gemm_p<PBF16>(a, s);
