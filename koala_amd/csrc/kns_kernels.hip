@@ -791,10 +791,11 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_kernel(GemmArgs g) {
 // or L2 inside the loop; LDS only double-buffers A tiles, kWs2Stage m-tiles per barrier.  The partner's second read of
 // an A tile hits the XCD's L2.
 constexpr int kWs2Stage = 2;    // m-tiles staged per barrier
-constexpr int kWs2Tiles = 7;    // n-tiles per wave (the 7th only on some waves)
+constexpr int kWs2Waves = 8;    // two waves per SIMD: one wave's MFMAs run under the other's epilogue VALU
+constexpr int kWs2Tiles = 4;    // n-tiles per wave (the 4th only on some waves): 26 / 8 -> 4,4,3,...
 
 template <int NB0>
-__global__ __launch_bounds__(256, 1) void gemm_ws2_kernel(GemmArgs g) {
+__global__ __launch_bounds__(64 * kWs2Waves, 2) void gemm_ws2_kernel(GemmArgs g) {
     typedef PBF16 P;
     typedef P::frag_t frag_t;
     constexpr int NB = P::NBH + NB0;
@@ -811,35 +812,29 @@ __global__ __launch_bounds__(256, 1) void gemm_ws2_kernel(GemmArgs g) {
     const int nt_base = half ? 26 : 0, nt_count = half ? kGateTiles - 26 : 26;
     const frag_t *w = (const frag_t *) g.w;
 
-    // this wave's n-tiles: nt_base + wave + 4 j; j < 6 always exists, j = 6 only on the first waves of a half
+    // this wave's n-tiles: nt_base + wave + 8 j; j < 3 always exists, j = 3 only on the first waves of a half
     int nt[kWs2Tiles];
 #pragma unroll
-    for (int j = 0; j < kWs2Tiles; ++j) nt[j] = nt_base + (wave + 4 * j < nt_count ? wave + 4 * j : 0);
-    const bool has7 = wave + 24 < nt_count;
-    frag_t wv[3][NB], wa[4][NB];
+    for (int j = 0; j < kWs2Tiles; ++j) nt[j] = nt_base + (wave + kWs2Waves * j < nt_count ? wave + kWs2Waves * j : 0);
+    const bool has4 = wave + kWs2Waves * 3 < nt_count;
+    frag_t wr[kWs2Tiles][NB];
     float bias[kWs2Tiles];
 #pragma unroll
     for (int j = 0; j < kWs2Tiles; ++j) {
 #pragma unroll
-        for (int blk = 0; blk < NB; ++blk) {
-            frag_t x = w[((size_t) nt[j] * NB + blk) * 64 + lane];
-            if (j < 3)
-                wv[j < 3 ? j : 0][blk] = x;
-            else
-                wa[j >= 3 ? j - 3 : 0][blk] = pin_to_agpr(x);
-        }
+        for (int blk = 0; blk < NB; ++blk) wr[j][blk] = w[((size_t) nt[j] * NB + blk) * 64 + lane];
         bias[j] = g.bias[nt[j] * 16 + colq];
     }
 
-    // A staging: block i of a stage (i = m * NB + blk; blk < NB0 is the y part) is fetched by wave i & 3.
+    // A staging: block i of a stage (i = m * NB + blk; blk < NB0 is the y part) is fetched by wave i % 8.
     // The launch guarantees mtiles % (kWs2Stage * gridDim.x / 2) == 0, so every staged m-tile exists.
     constexpr int kStageBlocks = kWs2Stage * NB;
-    constexpr int kFetch = (kStageBlocks + 3) / 4;
+    constexpr int kFetch = (kStageBlocks + kWs2Waves - 1) / kWs2Waves;
     const frag_t *src[kFetch];
     size_t step[kFetch];
 #pragma unroll
     for (int i = 0; i < kFetch; ++i) {
-        const int idx = wave + 4 * i;
+        const int idx = wave + kWs2Waves * i;
         const int m = idx / NB, blk = idx % NB;
         const int mt = mgroup * kWs2Stage + m;
         if (blk < NB0) {
@@ -852,7 +847,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ws2_kernel(GemmArgs g) {
     }
 #pragma unroll
     for (int i = 0; i < kFetch; ++i)
-        if (wave + 4 * i < kStageBlocks) abuf[(wave + 4 * i) * 64 + lane] = *src[i];
+        if (wave + kWs2Waves * i < kStageBlocks) abuf[(wave + kWs2Waves * i) * 64 + lane] = *src[i];
     __syncthreads();
 
     auto store_tile = [&](P::gi_t *out, int j, f32x4 v) {
@@ -868,48 +863,35 @@ __global__ __launch_bounds__(256, 1) void gemm_ws2_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < kFetch; ++i) {
             src[i] += step[i];
-            if (more && wave + 4 * i < kStageBlocks) stage[i] = *src[i];  // in flight during this stage's MFMAs
+            if (more && wave + kWs2Waves * i < kStageBlocks) stage[i] = *src[i];  // in flight during this stage's MFMAs
         }
 #pragma unroll
         for (int m = 0; m < kWs2Stage; ++m) {
             const frag_t *ab = abuf + (cur * kStageBlocks + m * NB) * 64;
-            frag_t a[NB];
-#pragma unroll
-            for (int blk = 0; blk < NB; ++blk) a[blk] = ab[blk * 64 + lane];
             P::gi_t *out = (P::gi_t *) g.out + (size_t) (mt0 + m) * kGateTiles * 64;
-            // n-tiles {0,1,2} from VGPRs, {3,4,5} from AGPRs: three independent accumulator chains each
+            // three independent accumulator chains over the always-present n-tiles; A fragments streamed from LDS
             f32x4 acc[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 acc3 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int blk = 0; blk < NB; ++blk)
+            for (int blk = 0; blk < NB; ++blk) {
+                const frag_t a = ab[blk * 64 + lane];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) acc[c] = P::mma(a[blk], wv[c][blk], acc[c]);
-            f32x4 acc2[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) acc2[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int blk = 0; blk < NB; ++blk)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) acc2[c] = P::mma(a[blk], wa[c][blk], acc2[c]);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) store_tile(out, c, acc[c]);
+                for (int c = 0; c < 3; ++c) acc[c] = P::mma(a, wr[c][blk], acc[c]);
+                if (has4) acc3 = P::mma(a, wr[3][blk], acc3);
+            }
             if (m == kWs2Stage - 1) {
-                // hand the next stage's A tiles to LDS here: the only VMEM younger than those loads are the three stores
-                // just issued, so the wait (vmcnt counts stores too on gfx950) is short
+                // hand the next stage's A tiles to LDS before this m-tile's stores are issued: vmcnt counts stores too on
+                // gfx950, so a wait placed after them would also wait for their write acknowledgements
 #pragma unroll
                 for (int i = 0; i < kFetch; ++i)
-                    if (more && wave + 4 * i < kStageBlocks)
-                        abuf[((cur ^ 1) * kStageBlocks + wave + 4 * i) * 64 + lane] = stage[i];
+                    if (more && wave + kWs2Waves * i < kStageBlocks)
+                        abuf[((cur ^ 1) * kStageBlocks + wave + kWs2Waves * i) * 64 + lane] = stage[i];
             }
 #pragma unroll
-            for (int c = 0; c < 3; ++c) store_tile(out, 3 + c, acc2[c]);
-            if (has7) {
-                f32x4 acc3 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int blk = 0; blk < NB; ++blk) acc3 = P::mma(a[blk], wa[3][blk], acc3);
-                store_tile(out, 6, acc3);
-            }
+            for (int c = 0; c < 3; ++c) store_tile(out, c, acc[c]);
+            if (has4) store_tile(out, 3, acc3);
         }
         __syncthreads();
         cur ^= 1;
@@ -1066,11 +1048,11 @@ void launch_gemm(const GemmArgs &a, hipStream_t s) {
                 hipLaunchKernelGGL(gemm_ws_kernel<2>, dim3(256), dim3(256), 0, s, a);
         } else {
             if (a.nb0 == 0)
-                hipLaunchKernelGGL(gemm_ws2_kernel<0>, dim3(256), dim3(256), 0, s, a);
+                hipLaunchKernelGGL(gemm_ws2_kernel<0>, dim3(256), dim3(64 * kWs2Waves), 0, s, a);
             else if (a.nb0 == 1)
-                hipLaunchKernelGGL(gemm_ws2_kernel<1>, dim3(256), dim3(256), 0, s, a);
+                hipLaunchKernelGGL(gemm_ws2_kernel<1>, dim3(256), dim3(64 * kWs2Waves), 0, s, a);
             else
-                hipLaunchKernelGGL(gemm_ws2_kernel<2>, dim3(256), dim3(256), 0, s, a);
+                hipLaunchKernelGGL(gemm_ws2_kernel<2>, dim3(256), dim3(64 * kWs2Waves), 0, s, a);
         }
         return;
     }
