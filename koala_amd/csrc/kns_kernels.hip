@@ -1450,9 +1450,182 @@ void launch_gru_small(const GruSmallArgs &a, hipStream_t s) {
         hipLaunchKernelGGL(gru_small_kernel<PF32>, grid, dim3(64), 0, s, a);
 }
 
+// ---- 8-wave form of the resident recurrent kernel.  Measured on MI355X: a single wave per SIMD executes its MFMAs and
+// its gate VALU one after the other (a unit tile costs 432 + ~650 cycles), while two waves on one SIMD overlap them.
+// Eight waves of <= 256 registers hold the 459 KiB of W_hh as: wave w owns unit tiles w and w + 8 (wave 0 also tile 16);
+// tile w entirely in VGPRs (27 fragments), the first 14 fragments of tile w + 8 in VGPRs and its last 13 in LDS, tile 16
+// in LDS: 328 KiB of registers + 131 KiB of LDS.  A fragments are re-read from LDS per k-block.
+constexpr int kR8Waves = 8;
+constexpr int kR8RegFrags1 = 14;                      // fragments of the second tile kept in registers
+constexpr int kR8LdsFrags1 = 27 - kR8RegFrags1;       // ... and in LDS
+constexpr int kR8Lds = 2 * PBF16::NBH * 1024 + kR8Waves * kR8LdsFrags1 * 1024 + 27 * 1024 + kResBiasBytes;
+
+// MFMAs of one unit tile whose fragments [first_lds, 27) live in LDS at wl[(i - first_lds)] (i = k_block * 3 + gate) and
+// the rest in wreg[i]; LDS fragments go through a kQ-deep register queue
+template <int kFirstLds, int kQ, int kNReg>
+__device__ __forceinline__ void r8_tile_mma(f32x4 (&acc)[3], const bf16x8 *ha, const bf16x8 (&wreg)[kNReg], const bf16x8 *wl,
+                                            int lane) {
+    constexpr int N = 27;
+    bf16x8 qb[kQ];
+#pragma unroll
+    for (int p = 0; p < kQ; ++p)
+        if (kFirstLds + p < N) qb[p] = wl[p * 64 + lane];
+    bf16x8 a = ha[lane];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (i % 3 == 0 && i > 0) a = ha[(i / 3) * 64 + lane];
+        bf16x8 b;
+        if (i < kFirstLds) {
+            b = wreg[i < kNReg ? i : 0];
+        } else {
+            const int j = i - kFirstLds;
+            b = qb[j % kQ];
+            if (i + kQ < N) qb[j % kQ] = wl[(j + kQ) * 64 + lane];
+        }
+        acc[i % 3] = PBF16::mma(a, b, acc[i % 3]);
+    }
+}
+
+__global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs g) {
+    typedef PBF16 P;
+    typedef P::frag_t frag_t;
+    constexpr int NBH = P::NBH;
+    __shared__ __attribute__((aligned(16))) char smem[kR8Lds];
+    char *hbuf0 = smem, *hbuf1 = smem + NBH * 1024;
+    frag_t *wl1 = (frag_t *) (smem + 2 * NBH * 1024);                                   // [8 waves][13][64]
+    frag_t *wl16 = (frag_t *) (smem + 2 * NBH * 1024 + kR8Waves * kR8LdsFrags1 * 1024);  // [27][64]
+    float *lbias = (float *) (smem + 2 * NBH * 1024 + kR8Waves * kR8LdsFrags1 * 1024 + 27 * 1024);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = blockIdx.x;
+    const int colq = lane & 15, rowq = (lane >> 4) * 4;
+    const frag_t *whh = (const frag_t *) g.whh;
+    const bool third = wave == 0;  // unit tile 16
+    const int u0 = wave, u1 = wave + 8, u2 = 16;
+
+    // ---- prologue
+    frag_t w0[27], w1[kR8RegFrags1];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) w0[i] = whh[((size_t) (u0 * 3 + i % 3) * NBH + i / 3) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < kR8RegFrags1; ++i) w1[i] = whh[((size_t) (u1 * 3 + i % 3) * NBH + i / 3) * 64 + lane];
+    frag_t *wl1w = wl1 + wave * kR8LdsFrags1 * 64;
+    for (int i = kR8RegFrags1; i < 27; ++i)
+        wl1w[(i - kR8RegFrags1) * 64 + lane] = whh[((size_t) (u1 * 3 + i % 3) * NBH + i / 3) * 64 + lane];
+    for (int i = wave; i < 27; i += kR8Waves) wl16[i * 64 + lane] = whh[((size_t) (u2 * 3 + i % 3) * NBH + i / 3) * 64 + lane];
+    for (int i = tid; i < kGateTiles * 16; i += 64 * kR8Waves) lbias[i] = g.bhh[i];
+
+    f32x4 hreg[3];
+    hreg[0] = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u0) * 64 + lane];
+    hreg[1] = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u1) * 64 + lane];
+    hreg[2] = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u2) * 64 + lane];
+    for (int i = tid; i < 2 * NBH * 64; i += 64 * kR8Waves) ((uint4 *) smem)[i] = uint4{0, 0, 0, 0};
+    __syncthreads();
+    auto put_h = [&](char *buf, int u, const f32x4 &h) {
+        const int k = u * 16 + colq;
+        uint16_t *dst = (uint16_t *) buf + (k / P::KB) * 64 * P::EPL + P::off(rowq, k % P::KB);
+        const uint32_t lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{h[0], h[1]}, bf16x2));
+        const uint32_t hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{h[2], h[3]}, bf16x2));
+        dst[0] = (uint16_t) lo;  // consecutive rows sit 8 elements apart in an A-packed block
+        dst[8] = (uint16_t) (lo >> 16);
+        dst[16] = (uint16_t) hi;
+        dst[24] = (uint16_t) (hi >> 16);
+    };
+    put_h(hbuf0, u0, hreg[0]);
+    put_h(hbuf0, u1, hreg[1]);
+    if (third) put_h(hbuf0, u2, hreg[2]);
+
+    P::gi_t gi[3][3];
+    {
+        const P::gi_t *gp = (const P::gi_t *) g.gi + (size_t) mt * kGateTiles * 64;
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt) {
+            gi[0][gt] = gp[(u0 * 3 + gt) * 64 + lane];
+            gi[1][gt] = gp[(u1 * 3 + gt) * 64 + lane];
+            gi[2][gt] = gp[(u2 * 3 + gt) * 64 + lane];
+        }
+    }
+    __syncthreads();
+
+    for (int t = 0; t < g.T; ++t) {
+        KNS_STAMP(0);
+        const char *hc = (t & 1) ? hbuf1 : hbuf0;
+        char *hn = (t & 1) ? hbuf0 : hbuf1;
+        const frag_t *ha = (const frag_t *) hc;
+        if (t > 0) {  // LDS holds h_{t-1}: publish it as the next layer's A operand
+            frag_t *hs = (frag_t *) g.hseq + ((size_t) (t - 1) * g.mtiles + mt) * NBH * 64;
+            for (int blk = wave; blk < NBH; blk += kR8Waves) hs[blk * 64 + lane] = ha[blk * 64 + lane];
+        }
+        const P::gi_t *gnext =
+            (const P::gi_t *) g.gi + ((size_t) (t + 1 < g.T ? t + 1 : t) * g.mtiles + mt) * kGateTiles * 64;
+
+        auto gates = [&](const int q, const int u, f32x4 (&acc)[3]) {
+            const f32x4 ir = P::from_gi(gi[q][0]), iz = P::from_gi(gi[q][1]), in = P::from_gi(gi[q][2]);
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt) gi[q][gt] = gnext[(u * 3 + gt) * 64 + lane];
+            const float br = lbias[(u * 3 + 0) * 16 + colq], bz = lbias[(u * 3 + 1) * 16 + colq],
+                        bn = lbias[(u * 3 + 2) * 16 + colq];
+            const f32x2 vbr = {br, br}, vbz = {bz, bz}, vbn = {bn, bn};
+            f32x4 hnew;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const f32x2 ar = {acc[0][2 * p], acc[0][2 * p + 1]}, az = {acc[1][2 * p], acc[1][2 * p + 1]},
+                            an = {acc[2][2 * p], acc[2][2 * p + 1]};
+                const f32x2 xr = {ir[2 * p], ir[2 * p + 1]}, xz = {iz[2 * p], iz[2 * p + 1]}, xn = {in[2 * p], in[2 * p + 1]};
+                const f32x2 r = fast_sigmoid2(xr + (ar + vbr));
+                const f32x2 z = fast_sigmoid2(xz + (az + vbz));
+                const f32x2 n = fast_tanh2(r * (an + vbn) + xn);
+                const f32x2 hp = {hreg[q][2 * p], hreg[q][2 * p + 1]};
+                const f32x2 h = z * (hp - n) + n;
+                hnew[2 * p] = h[0];
+                hnew[2 * p + 1] = h[1];
+            }
+            hreg[q] = hnew;
+            put_h(hn, u, hnew);
+        };
+
+        KNS_STAMP(1);
+        f32x4 acc[3];
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        r8_tile_mma<27, 1, 27>(acc, ha, w0, wl16, lane);
+        KNS_STAMP(2);
+        gates(0, u0, acc);
+        KNS_STAMP(3);
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        r8_tile_mma<kR8RegFrags1, 3, kR8RegFrags1>(acc, ha, w1, wl1w, lane);
+        KNS_STAMP(4);
+        gates(1, u1, acc);
+        KNS_STAMP(5);
+        if (third) {
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            r8_tile_mma<0, 4, 27>(acc, ha, w0, wl16, lane);
+            KNS_STAMP(6);
+            gates(2, u2, acc);
+        }
+        KNS_STAMP(7);
+        __syncthreads();
+        KNS_STAMP(8);
+    }
+    {
+        const char *hc = (g.T & 1) ? hbuf1 : hbuf0;
+        frag_t *hs = (frag_t *) g.hseq + ((size_t) (g.T - 1) * g.mtiles + mt) * NBH * 64;
+        for (int blk = wave; blk < NBH; blk += kR8Waves) hs[blk * 64 + lane] = ((const frag_t *) hc)[blk * 64 + lane];
+    }
+    ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u0) * 64 + lane] = hreg[0];
+    ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u1) * 64 + lane] = hreg[1];
+    if (third) ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u2) * 64 + lane] = hreg[2];
+}
+
 void launch_gru(const GruArgs &a, hipStream_t s) {
     static const bool stream_weights = getenv("KOALA_AMD_GRU_STREAM") != nullptr;  // A/B switch for profiling
-    if (a.precision == kBf16 && !stream_weights)
+    static const bool four_waves = getenv("KOALA_AMD_GRU_4WAVE") != nullptr;  // A/B switch: one wave per SIMD
+    if (a.precision == kBf16 && !stream_weights && !four_waves)
+        hipLaunchKernelGGL(gru_resident8_kernel, dim3(a.mtiles), dim3(64 * kR8Waves), 0, s, a);
+    else if (a.precision == kBf16 && !stream_weights)
         hipLaunchKernelGGL(gru_resident_kernel, dim3(a.mtiles), dim3(256), 0, s, a);
     else if (a.precision == kBf16)
         hipLaunchKernelGGL(gru_kernel<PBF16>, dim3(a.mtiles), dim3(256), 0, s, a);
