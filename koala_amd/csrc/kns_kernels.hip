@@ -1080,30 +1080,34 @@ void launch_gemm(const GemmArgs &a, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------ recurrent GRU
 
-template <class P>
-__global__ __launch_bounds__(256, P::kGruWaves) void gru_kernel(GruArgs g) {
+// Weights streamed from L2 every step (fp32 parity path; bf16 only as an A/B switch).  W waves per workgroup share the
+// 17 unit tiles round-robin; the B fragments of a tile are fetched two k-blocks (six fragments) ahead of their MFMAs, and with W = 8 two waves per SIMD cover each other's latencies.
+template <class P, int W>
+__global__ __launch_bounds__(64 * W, W / 4) void gru_kernel(GruArgs g) {
     typedef typename P::frag_t frag_t;
     typedef typename P::elem_t elem_t;
     constexpr int NBH = P::NBH;
+    constexpr int TPW = (kUnitTiles + W - 1) / W;  // unit tiles per wave
     __shared__ __attribute__((aligned(16))) char hbuf[2][NBH * 1024];  // operand-typed hidden state, A-packed
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mt = blockIdx.x;
     const int colq = lane & 15, rowq = (lane >> 4) * 4;
 
     // fp32 hidden state of the (row, unit) elements this lane owns
-    f32x4 hreg[kGruTilesPerWave];
+    f32x4 hreg[TPW];
 #pragma unroll
-    for (int q = 0; q < kGruTilesPerWave; ++q) {
-        const int u = wave + 4 * q;
+    for (int q = 0; q < TPW; ++q) {
+        const int u = wave + W * q;
         hreg[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (u < kUnitTiles) hreg[q] = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u) * 64 + lane];
     }
-    for (int i = tid; i < 2 * NBH * 64; i += 256) ((uint4 *) hbuf)[i] = uint4{0, 0, 0, 0};
+    for (int i = tid; i < 2 * NBH * 64; i += 64 * W) ((uint4 *) hbuf)[i] = uint4{0, 0, 0, 0};
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < kGruTilesPerWave; ++q) {
-        const int u = wave + 4 * q;
+    for (int q = 0; q < TPW; ++q) {
+        const int u = wave + W * q;
         if (u < kUnitTiles) {
             const int k = u * 16 + colq;
             elem_t *dst = (elem_t *) hbuf[0] + (k / P::KB) * 64 * P::EPL;
@@ -1117,19 +1121,14 @@ __global__ __launch_bounds__(256, P::kGruWaves) void gru_kernel(GruArgs g) {
     int cur = 0;
     for (int t = 0; t < g.T; ++t) {
         const frag_t *ha = (const frag_t *) hbuf[cur];
-        frag_t a[P::kHoldA ? NBH : 1];
-        if constexpr (P::kHoldA) {
-#pragma unroll
-            for (int blk = 0; blk < NBH; ++blk) a[blk] = ha[blk * 64 + lane];
-        }
         if (t > 0) {  // what is in LDS now is h_{t-1}: publish it as the next layer's A operand
             frag_t *hs = (frag_t *) g.hseq + ((size_t) (t - 1) * g.mtiles + mt) * NBH * 64;
-            for (int blk = wave; blk < NBH; blk += 4) hs[blk * 64 + lane] = ha[blk * 64 + lane];
+            for (int blk = wave; blk < NBH; blk += W) hs[blk * 64 + lane] = ha[blk * 64 + lane];
         }
         const typename P::gi_t *gi = (const typename P::gi_t *) g.gi + ((size_t) t * g.mtiles + mt) * kGateTiles * 64;
 #pragma unroll
-        for (int q = 0; q < kGruTilesPerWave; ++q) {
-            const int u = wave + 4 * q;
+        for (int q = 0; q < TPW; ++q) {
+            const int u = wave + W * q;
             if (u < kUnitTiles) {
                 typename P::gi_t gir = gi[(u * 3 + 0) * 64 + lane];
                 typename P::gi_t giz = gi[(u * 3 + 1) * 64 + lane];
@@ -1137,25 +1136,31 @@ __global__ __launch_bounds__(256, P::kGruWaves) void gru_kernel(GruArgs g) {
                 f32x4 acc[3];
 #pragma unroll
                 for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (P::kHoldA) {
+                // B fragments two k-blocks ahead of their MFMAs, rotated through registers (a rolled loop: unrolling all 51
+                // fp32 k-block/gate pairs makes hipcc materialise an address pair per load and spill)
+                const frag_t *wu = whh + (size_t) u * 3 * NBH * 64 + lane;
+                frag_t b0[3], b1[3], b2[3];
 #pragma unroll
-                    for (int blk = 0; blk < NBH; ++blk) {
-#pragma unroll
-                        for (int gt = 0; gt < 3; ++gt) {
-                            frag_t b = whh[((size_t) (u * 3 + gt) * NBH + blk) * 64 + lane];
-                            acc[gt] = P::mma(a[blk], b, acc[gt]);
-                        }
-                    }
-                } else {
+                for (int gt = 0; gt < 3; ++gt) {
+                    b0[gt] = wu[(gt * NBH + 0) * 64];
+                    b1[gt] = wu[(gt * NBH + 1) * 64];
+                    b2[gt] = wu[(gt * NBH + 2) * 64];
+                }
 #pragma nounroll
-                    for (int blk = 0; blk < NBH; ++blk) {
-                        const frag_t ab = ha[blk * 64 + lane];
+                for (int blk = 0; blk < NBH; ++blk) {
+                    const frag_t ab = ha[blk * 64 + lane];
+                    frag_t bc[3];
 #pragma unroll
-                        for (int gt = 0; gt < 3; ++gt) {
-                            frag_t b = whh[((size_t) (u * 3 + gt) * NBH + blk) * 64 + lane];
-                            acc[gt] = P::mma(ab, b, acc[gt]);
-                        }
+                    for (int gt = 0; gt < 3; ++gt) {
+                        bc[gt] = b0[gt];
+                        b0[gt] = b1[gt];
+                        b1[gt] = b2[gt];
                     }
+                    const int nb = blk + 3 < NBH ? blk + 3 : NBH - 1;
+#pragma unroll
+                    for (int gt = 0; gt < 3; ++gt) b2[gt] = wu[(gt * NBH + nb) * 64];
+#pragma unroll
+                    for (int gt = 0; gt < 3; ++gt) acc[gt] = P::mma(ab, bc[gt], acc[gt]);
                 }
                 const float br = g.bhh[(u * 3 + 0) * 16 + colq];
                 const float bz = g.bhh[(u * 3 + 1) * 16 + colq];
@@ -1179,11 +1184,11 @@ __global__ __launch_bounds__(256, P::kGruWaves) void gru_kernel(GruArgs g) {
     }
     {
         frag_t *hs = (frag_t *) g.hseq + ((size_t) (g.T - 1) * g.mtiles + mt) * NBH * 64;
-        for (int blk = wave; blk < NBH; blk += 4) hs[blk * 64 + lane] = ((const frag_t *) hbuf[cur])[blk * 64 + lane];
+        for (int blk = wave; blk < NBH; blk += W) hs[blk * 64 + lane] = ((const frag_t *) hbuf[cur])[blk * 64 + lane];
     }
 #pragma unroll
-    for (int q = 0; q < kGruTilesPerWave; ++q) {
-        const int u = wave + 4 * q;
+    for (int q = 0; q < TPW; ++q) {
+        const int u = wave + W * q;
         if (u < kUnitTiles) ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u) * 64 + lane] = hreg[q];
     }
 }
@@ -1628,9 +1633,9 @@ void launch_gru(const GruArgs &a, hipStream_t s) {
     else if (a.precision == kBf16 && !stream_weights)
         hipLaunchKernelGGL(gru_resident_kernel, dim3(a.mtiles), dim3(256), 0, s, a);
     else if (a.precision == kBf16)
-        hipLaunchKernelGGL(gru_kernel<PBF16>, dim3(a.mtiles), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((gru_kernel<PBF16, 8>), dim3(a.mtiles), dim3(512), 0, s, a);
     else
-        hipLaunchKernelGGL(gru_kernel<PF32>, dim3(a.mtiles), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((gru_kernel<PF32, 8>), dim3(a.mtiles), dim3(512), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------ reset
