@@ -47,6 +47,8 @@ def main():
     ap.add_argument('--frames', type=int, default=32, help='frames per stream per call')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL over xGMI) for real runs; gloo only to test the '
+                    'multi-rank code path on a single-GPU box together with KOALA_BENCH_SHARE_GPU=1')
     args = ap.parse_args()
 
     import numpy as np
@@ -60,12 +62,17 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if os.environ.get('KOALA_BENCH_SHARE_GPU'):
+        local_rank = 0  # test mode: every rank drives GPU 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
     else:
         torch.cuda.set_device(local_rank)
     if args.gpus != world and rank == 0 and world > 1:
