@@ -1495,19 +1495,25 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     typedef PBF16 P;
     typedef P::frag_t frag_t;
     constexpr int NBH = P::NBH;
-    __shared__ __attribute__((aligned(16))) char smem[kR8Lds];
+    __shared__ __attribute__((aligned(16))) char smem[kR8Lds + 3 * 1024];
     char *hbuf0 = smem, *hbuf1 = smem + NBH * 1024;
     frag_t *wl1 = (frag_t *) (smem + 2 * NBH * 1024);                                   // [8 waves][13][64]
-    frag_t *wl16 = (frag_t *) (smem + 2 * NBH * 1024 + kR8Waves * kR8LdsFrags1 * 1024);  // [27][64]
+    frag_t *wl16 = (frag_t *) (smem + 2 * NBH * 1024 + kR8Waves * kR8LdsFrags1 * 1024);  // [27][64], i = blk * 3 + gate
     float *lbias = (float *) (smem + 2 * NBH * 1024 + kR8Waves * kR8LdsFrags1 * 1024 + 27 * 1024);
+    f32x4 *acc16 = (f32x4 *) (smem + kR8Lds);  // [3 gates][64 lanes]: unit tile 16's accumulators, handed across waves
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mt = blockIdx.x;
     const int colq = lane & 15, rowq = (lane >> 4) * 4;
     const frag_t *whh = (const frag_t *) g.whh;
-    const bool third = wave == 0;  // unit tile 16
     const int u0 = wave, u1 = wave + 8, u2 = 16;
+    // Unit tile 16 (the 17th) would make one wave's serial chain 3 tiles long while the others wait at the barrier.
+    // Its 27 MFMAs are done by waves 5, 6, 7 (one gate each, the full k chain in one accumulator, so the arithmetic is
+    // unchanged), the accumulators cross LDS, and after a barrier waves 0..3 each do the gate math of one of the four
+    // rows a lane owns.
+    const int g16 = wave - 5;         // gate whose tile-16 MFMAs this wave computes (waves 5..7)
+    const bool q16 = wave < 4;        // this wave finishes row (lane >> 4) * 4 + wave of tile 16
 
     // ---- prologue
     frag_t w0[27], w1[kR8RegFrags1];
@@ -1521,10 +1527,11 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     for (int i = wave; i < 27; i += kR8Waves) wl16[i * 64 + lane] = whh[((size_t) (u2 * 3 + i % 3) * NBH + i / 3) * 64 + lane];
     for (int i = tid; i < kGateTiles * 16; i += 64 * kR8Waves) lbias[i] = g.bhh[i];
 
-    f32x4 hreg[3];
+    f32x4 hreg[2];
     hreg[0] = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u0) * 64 + lane];
     hreg[1] = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u1) * 64 + lane];
-    hreg[2] = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u2) * 64 + lane];
+    const int e16 = q16 ? wave : 0;  // element of the f32x4 this wave owns in tile 16
+    float h16 = g.hstate_in[(((size_t) mt * kUnitTiles + u2) * 64 + lane) * 4 + e16];
     for (int i = tid; i < 2 * NBH * 64; i += 64 * kR8Waves) ((uint4 *) smem)[i] = uint4{0, 0, 0, 0};
     __syncthreads();
     auto put_h = [&](char *buf, int u, const f32x4 &h) {
@@ -1537,18 +1544,23 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
         dst[16] = (uint16_t) hi;
         dst[24] = (uint16_t) (hi >> 16);
     };
+    auto put_h16 = [&](char *buf, float h) {  // one row of tile 16
+        const int k = u2 * 16 + colq;
+        uint16_t *dst = (uint16_t *) buf + (k / P::KB) * 64 * P::EPL + P::off(rowq + e16, k % P::KB);
+        dst[0] = f2bf(h);
+    };
     put_h(hbuf0, u0, hreg[0]);
     put_h(hbuf0, u1, hreg[1]);
-    if (third) put_h(hbuf0, u2, hreg[2]);
+    if (q16) put_h16(hbuf0, h16);
 
-    P::gi_t gi[3][3];
+    P::gi_t gi[2][3], gi16[3];
     {
         const P::gi_t *gp = (const P::gi_t *) g.gi + (size_t) mt * kGateTiles * 64;
 #pragma unroll
         for (int gt = 0; gt < 3; ++gt) {
             gi[0][gt] = gp[(u0 * 3 + gt) * 64 + lane];
             gi[1][gt] = gp[(u1 * 3 + gt) * 64 + lane];
-            gi[2][gt] = gp[(u2 * 3 + gt) * 64 + lane];
+            gi16[gt] = gp[(u2 * 3 + gt) * 64 + lane];
         }
     }
     __syncthreads();
@@ -1604,12 +1616,38 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
         KNS_STAMP(4);
         gates(1, u1, acc);
         KNS_STAMP(5);
-        if (third) {
+        if (g16 >= 0) {  // waves 5, 6, 7: one gate of unit tile 16, k-blocks in order in one accumulator
+            f32x4 a16 = f32x4{0.f, 0.f, 0.f, 0.f};
+            frag_t qb[3];
 #pragma unroll
-            for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            r8_tile_mma<0, 4, 27>(acc, ha, w0, wl16, lane);
-            KNS_STAMP(6);
-            gates(2, u2, acc);
+            for (int p = 0; p < 3; ++p) qb[p] = wl16[(p * 3 + g16) * 64 + lane];
+#pragma unroll
+            for (int blk = 0; blk < NBH; ++blk) {
+                const frag_t a = ha[blk * 64 + lane];
+                const frag_t b = qb[blk % 3];
+                if (blk + 3 < NBH) qb[blk % 3] = wl16[((blk + 3) * 3 + g16) * 64 + lane];
+                a16 = P::mma(a, b, a16);
+            }
+            acc16[g16 * 64 + lane] = a16;
+        }
+        KNS_STAMP(6);
+        __syncthreads();
+        if (q16) {  // waves 0..3: row e16 of every lane's four rows of unit tile 16
+            const float ar = ((const float *) acc16)[(0 * 64 + lane) * 4 + e16];
+            const float az = ((const float *) acc16)[(1 * 64 + lane) * 4 + e16];
+            const float an = ((const float *) acc16)[(2 * 64 + lane) * 4 + e16];
+            const float xr = (float) gi16[0][e16], xz = (float) gi16[1][e16], xn = (float) gi16[2][e16];
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt) gi16[gt] = gnext[(u2 * 3 + gt) * 64 + lane];
+            const float br = lbias[(u2 * 3 + 0) * 16 + colq], bz = lbias[(u2 * 3 + 1) * 16 + colq],
+                        bn = lbias[(u2 * 3 + 2) * 16 + colq];
+            // same operations, element by element, as the packed gate math above
+            const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((xr + (ar + br)) * -1.44269504088896341f));
+            const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((xz + (az + bz)) * -1.44269504088896341f));
+            const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((r * (an + bn) + xn) * 2.88539008177792681f));
+            const float n = 1.0f - (rr + rr);
+            h16 = z * (h16 - n) + n;
+            put_h16(hn, h16);
         }
         KNS_STAMP(7);
         __syncthreads();
@@ -1622,7 +1660,7 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     }
     ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u0) * 64 + lane] = hreg[0];
     ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u1) * 64 + lane] = hreg[1];
-    if (third) ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u2) * 64 + lane] = hreg[2];
+    if (q16) g.hstate_out[(((size_t) mt * kUnitTiles + u2) * 64 + lane) * 4 + e16] = h16;
 }
 
 void launch_gru(const GruArgs &a, hipStream_t s) {

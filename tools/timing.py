@@ -28,5 +28,5 @@ w2 = np.array(buf[32:41], dtype=np.int64)
 pass
 print('ws gemm:', {n: int(d) for n, d in zip(['stage issue + A read', 'tile0', 'tile1', 'tile2', 'tile3', 'tile4', 'stage write', 'barrier'], np.diff(w))})
 print('stamps (s_memtime ticks rel.):', (t - t[0]).tolist())
-names = ['top (hseq store)', 'mfma0', 'gates0', 'mfma1', 'gates1', 'mfma2', 'gates2', 'barrier']
+names = ['top (hseq store)', 'mfma0', 'gates0', 'mfma1', 'gates1', 'tile16 mfma (w5-7)', 'barrier A + tile16 gates', 'barrier B']
 print({n: int(d) for n, d in zip(names, np.diff(t))})
