@@ -541,7 +541,11 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     sy.twiddle = d_twiddle_;
     sy.tail_in = d_tail_[tail_cur_];
     sy.tail_out = d_tail_[in_place ? tail_cur_ : tail_cur_ ^ 1];
-    sy.seg = T <= 4 ? T : 4;
+    static const int seg_env = getenv("KOALA_AMD_SYNTH_SEG") ? atoi(getenv("KOALA_AMD_SYNTH_SEG")) : 0;
+    // two segments per stream tile (512 workgroups at B = 4096) measured best: fewer, longer segments amortise the
+    // one replayed frame; a single segment leaves half the chip without a second workgroup to overlap with
+    const int seg = seg_env > 0 ? seg_env : (T <= 4 ? T : (T + 1) / 2 > 4 ? (T + 1) / 2 : 4);
+    sy.seg = T <= seg ? T : seg;
     sy.out = d_out;
     sy.B = B_;
     sy.Bpad = Bpad_;

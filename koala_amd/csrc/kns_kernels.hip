@@ -155,13 +155,13 @@ struct PBF16 {
 
 // ------------------------------------------------------------------------------------------------ FFT-256 per wave
 
-struct cpx {
-    float x, y;
-};
-__device__ __forceinline__ cpx cadd(cpx a, cpx b) { return {a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ cpx csub(cpx a, cpx b) { return {a.x - b.x, a.y - b.y}; }
+// complex numbers as packed pairs: add/sub are one v_pk_add_f32, a complex multiply is v_pk_mul_f32 + v_pk_fma_f32
+typedef float cpx __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cpx cadd(cpx a, cpx b) { return a + b; }
+__device__ __forceinline__ cpx csub(cpx a, cpx b) { return a - b; }
 __device__ __forceinline__ cpx cmul(cpx a, cpx w) {
-    return {__builtin_fmaf(a.x, w.x, -(a.y * w.y)), __builtin_fmaf(a.x, w.y, a.y * w.x)};
+    const cpx t = cpx{a.y, a.y} * cpx{-w.y, w.x};
+    return __builtin_elementwise_fma(cpx{a.x, a.x}, w, t);
 }
 
 __device__ __forceinline__ void radix4(cpx (&v)[4]) {
@@ -173,38 +173,30 @@ __device__ __forceinline__ void radix4(cpx (&v)[4]) {
     v[3] = csub(a1, a3);
 }
 
-// LDS exchange buffers of the wave FFT.  Padding them (i -> i + (i >> 5)) removes the 4-way ds_write_b32 conflicts of
-// the first two radix-4 stages but was measured SLOWER on MI355X (synthesis 246 vs 193 us): the extra address VALU
-// costs more than the conflicts, so the buffers are left linear.
-constexpr int kFftPad = 256;               // floats per re / im array
-constexpr int kFftBufFloats = 4 * kFftPad;  // two ping-pong buffers of {re, im}
-__device__ __forceinline__ int fpad(int i) { return i; }
+// LDS exchange buffers of the wave FFT: two ping-pong arrays of 256 interleaved complex values (ds_read/write_b64
+// straight into the packed register pairs).  Padding them against the 4-way write conflicts of the first two radix-4
+// stages was measured SLOWER on MI355X (synthesis 246 vs 193 us): the extra address VALU costs more than the conflicts.
+constexpr int kFftBufFloats = 4 * 256;  // per wave: 2 buffers x 256 complex
 
 // Forward 256-point complex FFT of one wavefront, radix-4 Stockham autosort.  On entry v[r] = z[lane + 64 r].
-// `buf` is this wave's LDS scratch (kFftBufFloats).  On return the spectrum is in natural order in the first buffer
-// (re at fpad(k), im at kFftPad + fpad(k)) and visible to the whole wave.  tw = exp(-2 pi i k / 512), k = 0..511, in LDS.
+// `buf` is this wave's LDS scratch (kFftBufFloats floats).  On return the spectrum is in natural order in the first
+// buffer (((cpx *) buf)[k]) and visible to the whole wave.  tw = exp(-2 pi i k / 512), k = 0..511, in LDS.
 __device__ __forceinline__ void fft256_wave(cpx (&v)[4], float *buf, const float2 *tw, int lane) {
-    float *b0 = buf, *b1 = buf + 2 * kFftPad;
+    cpx *b0 = (cpx *) buf, *b1 = (cpx *) buf + 256;
     // stage Ns = 1 (all twiddles are 1)
     radix4(v);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        b1[fpad(4 * lane + r)] = v[r].x;
-        b1[kFftPad + fpad(4 * lane + r)] = v[r].y;
-    }
+    for (int r = 0; r < 4; ++r) b1[4 * lane + r] = v[r];
     wave_lds_sync();
     // stages Ns = 4, 16, 64
 #pragma unroll
     for (int s = 1; s < 4; ++s) {
         const int Ns = 1 << (2 * s);
-        float *src = (s & 1) ? b1 : b0;
-        float *dst = (s & 1) ? b0 : b1;
+        cpx *src = (s & 1) ? b1 : b0;
+        cpx *dst = (s & 1) ? b0 : b1;
         const int k = lane & (Ns - 1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            v[r].x = src[fpad(lane + 64 * r)];
-            v[r].y = src[kFftPad + fpad(lane + 64 * r)];
-        }
+        for (int r = 0; r < 4; ++r) v[r] = src[lane + 64 * r];
 #pragma unroll
         for (int r = 1; r < 4; ++r) {
             float2 w = tw[r * k * (128 / Ns)];
@@ -213,10 +205,7 @@ __device__ __forceinline__ void fft256_wave(cpx (&v)[4], float *buf, const float
         radix4(v);
         const int j0 = (lane / Ns) * Ns * 4 + k;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            dst[fpad(j0 + r * Ns)] = v[r].x;
-            dst[kFftPad + fpad(j0 + r * Ns)] = v[r].y;
-        }
+        for (int r = 0; r < 4; ++r) dst[j0 + r * Ns] = v[r];
         wave_lds_sync();
     }
     // s = 1 -> b0, s = 2 -> b1, s = 3 -> b0: result is in b0
@@ -287,8 +276,9 @@ __global__ __launch_bounds__(256) void analysis_kernel(AnalysisArgs g) {
         for (int r = 0; r < 4; ++r) {
             const int k = lane + 64 * r;
             const int kc = (256 - k) & 255;
-            cpx zk = {buf[fpad(k)], buf[kFftPad + fpad(k)]};
-            cpx zc = {buf[fpad(kc)], -buf[kFftPad + fpad(kc)]};
+            const cpx zk = ((const cpx *) buf)[k];
+            cpx zc = ((const cpx *) buf)[kc];
+            zc.y = -zc.y;
             float2 w = tw[k];
             cpx s = cadd(zk, zc), d = csub(zk, zc);
             cpx p = cmul(d, cpx{w.x, w.y});
@@ -449,8 +439,9 @@ __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
             for (int r = 0; r < 4; ++r) {
                 const int n = lane + 64 * r;
                 // swapped output: re <-> im
-                float x0 = buf[kFftPad + fpad(n)] * (1.0f / 256.0f);
-                float x1 = buf[fpad(n)] * (1.0f / 256.0f);
+                const cpx zz = ((const cpx *) buf)[n];
+                float x0 = zz.y * (1.0f / 256.0f);
+                float x1 = zz.x * (1.0f / 256.0f);
                 float y0 = x0 * win[2 * n], y1 = x1 * win[2 * n + 1];
                 if (r < 2) {
                     float a0 = (tl[f][r].x + y0) * 32768.0f, a1 = (tl[f][r].y + y1) * 32768.0f;
