@@ -781,11 +781,10 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_kernel(GemmArgs g) {
 // them in registers (3 n-tiles in VGPRs, 4 pinned in AGPRs), including the y_prev part.  No weight ever comes from LDS
 // or L2 inside the loop; LDS only double-buffers A tiles, kWs2Stage m-tiles per barrier.  The partner's second read of
 // an A tile hits the XCD's L2.
-constexpr int kWs2Stage = 2;    // m-tiles staged per barrier
 constexpr int kWs2Waves = 8;    // two waves per SIMD: one wave's MFMAs run under the other's epilogue VALU
 constexpr int kWs2Tiles = 4;    // n-tiles per wave (the 4th only on some waves): 26 / 8 -> 4,4,3,...
 
-template <int NB0>
+template <int NB0, int kWs2Stage>  // kWs2Stage: m-tiles staged per barrier
 __global__ __launch_bounds__(64 * kWs2Waves, 2) void gemm_ws2_kernel(GemmArgs g) {
     typedef PBF16 P;
     typedef P::frag_t frag_t;
@@ -1030,20 +1029,26 @@ void launch_gemm(const GemmArgs &a, hipStream_t s) {
     if (a.precision == kBf16 && a.out_kind == kOutGi && a.ntiles == kGateTiles && a.nb1 == PBF16::NBH && a.nb0 <= 2 &&
         a.mtiles >= 256 && !no_ws) {
         static const bool ws1 = getenv("KOALA_AMD_GEMM_WS1") != nullptr;  // A/B switch: first weight-stationary form
-        if (ws1 || a.mtiles % (128 * kWs2Stage) != 0) {
+        const dim3 grid(256), block(64 * kWs2Waves);
+        if (ws1 || a.mtiles % 256 != 0) {
             if (a.nb0 == 0)
                 hipLaunchKernelGGL(gemm_ws_kernel<0>, dim3(256), dim3(256), 0, s, a);
             else if (a.nb0 == 1)
                 hipLaunchKernelGGL(gemm_ws_kernel<1>, dim3(256), dim3(256), 0, s, a);
             else
                 hipLaunchKernelGGL(gemm_ws_kernel<2>, dim3(256), dim3(256), 0, s, a);
+        } else if (a.mtiles % 512 == 0 && a.nb0 < 2) {  // four m-tiles per barrier (NB0 = 2 would spill)
+            if (a.nb0 == 0)
+                hipLaunchKernelGGL((gemm_ws2_kernel<0, 4>), grid, block, 0, s, a);
+            else
+                hipLaunchKernelGGL((gemm_ws2_kernel<1, 4>), grid, block, 0, s, a);
         } else {
             if (a.nb0 == 0)
-                hipLaunchKernelGGL(gemm_ws2_kernel<0>, dim3(256), dim3(64 * kWs2Waves), 0, s, a);
+                hipLaunchKernelGGL((gemm_ws2_kernel<0, 2>), grid, block, 0, s, a);
             else if (a.nb0 == 1)
-                hipLaunchKernelGGL(gemm_ws2_kernel<1>, dim3(256), dim3(64 * kWs2Waves), 0, s, a);
+                hipLaunchKernelGGL((gemm_ws2_kernel<1, 2>), grid, block, 0, s, a);
             else
-                hipLaunchKernelGGL(gemm_ws2_kernel<2>, dim3(256), dim3(64 * kWs2Waves), 0, s, a);
+                hipLaunchKernelGGL((gemm_ws2_kernel<2, 2>), grid, block, 0, s, a);
         }
         return;
     }
