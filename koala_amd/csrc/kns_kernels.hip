@@ -1005,6 +1005,74 @@ __global__ __launch_bounds__(512, 2) void gemm_wsr_kernel(GemmArgs g) {
     }
 }
 
+// ---- narrow heads (271 -> 1, 5, 40; bf16): the whole weight image is only 2-4 n-tiles, so every wave keeps ALL of it
+// in registers and the waves split the m-tiles instead of the n-tiles: no LDS staging, no barrier, A fragments
+// double-buffered in registers straight from HBM.  (With the n-tiles split over waves one or two waves did all the
+// sigmoids of a workgroup and the kernel was VALU-bound at 36 us; this form is bound by reading A.)
+template <int NT>  // n-tiles (2 or 4)
+__global__ __launch_bounds__(512, 2) void gemm_head_kernel(GemmArgs g) {
+    typedef PBF16 P;
+    typedef P::frag_t frag_t;
+    constexpr int NB = P::NBH;
+    __shared__ __attribute__((aligned(16))) char smem[8 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint16_t *sc = (uint16_t *) (smem + wave * 1024);  // this wave's transposer: C-fragments -> one A-packed block
+    const int colq = lane & 15;
+    const frag_t *w = (const frag_t *) g.w;
+    frag_t wr[NT][NB];
+    float bias[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) wr[j][blk] = w[((size_t) j * NB + blk) * 64 + lane];
+        bias[j] = g.bias[j * 16 + colq];
+    }
+    const frag_t *a1p = (const frag_t *) g.a1;
+    const int stride = gridDim.x * 8;
+    int mt = blockIdx.x * 8 + wave;
+    frag_t an[NB];
+    if (mt < g.mtiles) {
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) an[blk] = a1p[((size_t) mt * NB + blk) * 64 + lane];
+    }
+    for (; mt < g.mtiles; mt += stride) {
+        frag_t a[NB];
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) a[blk] = an[blk];
+        if (mt + stride < g.mtiles) {
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) an[blk] = a1p[((size_t) (mt + stride) * NB + blk) * 64 + lane];
+        }
+#pragma unroll
+        for (int pair = 0; pair < NT / 2; ++pair) {
+            f32x4 acc[2];
+            acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = P::mma(a[blk], wr[pair * 2 + j][blk], acc[j]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nt = pair * 2 + j;
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (nt * 16 < g.n_valid) {  // an n-tile made of padding columns only needs no sigmoid
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float x = kns_sigmoid(acc[j][i] + bias[nt]);
+                        v[i] = nt * 16 + colq < g.n_valid ? x : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sc[P::off((lane >> 4) * 4 + i, j * 16 + colq)] = P::cvt(v[i]);
+            }
+            wave_lds_sync();
+            ((uint4 *) g.out)[((size_t) mt * (NT / 2) + pair) * 64 + lane] = ((const uint4 *) sc)[lane];
+            wave_lds_sync();
+        }
+    }
+}
+
 template <class P>
 static void launch_gemm_p(const GemmArgs &a, hipStream_t s) {
     const int nb = a.nb0 + a.nb1;
@@ -1057,6 +1125,14 @@ void launch_gemm(const GemmArgs &a, hipStream_t s) {
         const dim3 grid(256), block(512);
         if (a.out_kind == kOutAPlain && a.ntiles <= 32) {
             hipLaunchKernelGGL((gemm_wsr_kernel<kOutAPlain, 2>), grid, block, 0, s, a);
+            return;
+        }
+        if (a.out_kind == kOutASigmoid && a.ntiles == 2) {
+            hipLaunchKernelGGL(gemm_head_kernel<2>, grid, block, 0, s, a);
+            return;
+        }
+        if (a.out_kind == kOutASigmoid && a.ntiles == 4) {
+            hipLaunchKernelGGL(gemm_head_kernel<4>, grid, block, 0, s, a);
             return;
         }
         if (a.out_kind == kOutASigmoid && a.ntiles <= 16) {
