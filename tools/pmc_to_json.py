@@ -7,7 +7,7 @@ import json
 import re
 import sys
 
-CLASS = {'analysis_kernel': 'analysis', 'gemm_ws2_kernel<0>': 'gemm_input', 'gru_resident_kernel': 'gru_recurrent',
+CLASS = {'analysis_kernel': 'analysis', 'gemm_ws2_kernel<0, 4>': 'gemm_input', 'gru_resident8_kernel': 'gru_recurrent',
          'synthesis_kernel': 'synthesis', 'gemm_wsr_kernel<2, 2>': 'gemm_head'}
 
 
