@@ -174,3 +174,23 @@ def test_mute_model_gives_silence():
     kb = koala_amd.create_batch('key', 5, 4, 'fp32', model_path=model)
     assert not kb.process(x).any()
     kb.delete()
+
+
+@pytest.mark.parametrize('precision,B,T', [('bf16', 1000, 5), ('bf16', 520, 3), ('fp32', 300, 2)])
+def test_ragged_large_batches_take_the_fallback_kernels(random_model, precision, B, T):
+    """Stream counts that are not multiples of 16 and m-tile counts that are not multiples of 256/512: these go through
+    the non-split weight-stationary GEMM and the generic kernels.  Every replica of the 8 distinct inputs must be
+    bit-identical wherever it sits, and the first 8 streams must match the oracle."""
+    base = synth_streams(8, T, seed=31)
+    x = np.tile(base, (B // 8 + 1, 1))[:B]
+    kb = koala_amd.create_batch('key', B, T, precision, model_path=random_model)
+    y = kb.process(x)
+    y2 = kb.process(x)
+    kb.delete()
+    for i in range(B):
+        assert np.array_equal(y[i], y[i % 8]), i
+        assert np.array_equal(y2[i], y2[i % 8]), i
+    o = oracle.Oracle(random_model, 8, oracle.PREC_BF16 if precision == 'bf16' else oracle.PREC_FP32)
+    ref = np.concatenate([o.process(base), o.process(base)], axis=1)
+    got = np.concatenate([y[:8], y2[:8]], axis=1)
+    assert lsb(got, ref).max() <= (6 if precision == 'bf16' else 1)
