@@ -1,0 +1,280 @@
+// kns_device.hpp -- device-side building blocks shared by the kernel translation units: the KNS-v1 scalar math
+// (DESIGN.md section 2), the two precision traits (MFMA instruction + fragment packing), the wave-level FFT-256, and
+// the helpers of the weight-resident kernels.
+// Hand-written gfx950 (CDNA4) kernels of the KNS-v1 noise suppressor: kns_stft.hip, kns_gemm.hip, kns_gru.hip.
+//
+// Hot path of pv_koala_process (reference include/pv_koala.h:65-80), batched over B independent streams and
+// T frames per call:
+//   analysis_kernel   a2+a3  int16 -> window -> real FFT-512 (radix-4 Stockham, one frame per wavefront, LDS
+//                            exchange) -> log-power features, written in MFMA A-fragment order
+//   gemm_kernel       a4     every input-side / front-end / head GEMM: A tile staged once in LDS in fragment
+//                            order, weights streamed from L2 in B-fragment order, MFMA 16x16x32 bf16 or 16x16x4 f32
+//   gru_kernel        a4     recurrent half of a GRU layer: one workgroup owns 16 streams for all T frames, hidden
+//                            state in registers (fp32) and LDS (operand type), no inter-workgroup traffic
+//   synthesis_kernel  a5     mask x spectrum -> inverse real FFT -> window -> overlap-add -> saturated int16
+//
+// Numerics follow DESIGN.md section 2 exactly (k-ascending fmaf chains, polynomial exp/log built from IEEE ops),
+// compiled with -ffp-contract=off so that no operation is fused or split behind the spec's back.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "kns_kernels.h"
+
+namespace kns {
+
+#ifdef KNS_TIMING
+static __device__ unsigned long long g_kns_timing[64];
+#define KNS_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && t == 5) g_kns_timing[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define KNS_STAMP(i) do { } while (0)
+#endif
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------ scalar math
+
+__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+__device__ __forceinline__ uint16_t f2bf(float x) {  // round to nearest even
+    uint32_t u = f2u(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t) (u >> 16);
+}
+
+__device__ __forceinline__ float kns_exp(float x) {
+    x = __builtin_fminf(__builtin_fmaxf(x, -87.0f), 88.0f);
+    float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float z = r * r;
+    float y = __builtin_fmaf(p, z, r) + 1.0f;
+    int ni = (int) n;
+    return y * u2f((uint32_t) (ni + 127) << 23);
+}
+
+__device__ __forceinline__ float kns_log(float x) {
+    uint32_t u = f2u(x);
+    int e = (int) ((u >> 23) & 0xffu) - 126;
+    float m = u2f((u & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.707106781186547524f) {
+        e -= 1;
+        m = (m + m) - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    float z = m * m;
+    float p = 7.0376836292e-2f;
+    p = __builtin_fmaf(p, m, -1.1514610310e-1f);
+    p = __builtin_fmaf(p, m, 1.1676998740e-1f);
+    p = __builtin_fmaf(p, m, -1.2420140846e-1f);
+    p = __builtin_fmaf(p, m, 1.4249322787e-1f);
+    p = __builtin_fmaf(p, m, -1.6668057665e-1f);
+    p = __builtin_fmaf(p, m, 2.0000714765e-1f);
+    p = __builtin_fmaf(p, m, -2.4999993993e-1f);
+    p = __builtin_fmaf(p, m, 3.3333331174e-1f);
+    float fe = (float) e;
+    float y = (p * m) * z;
+    y = __builtin_fmaf(fe, -2.12194440e-4f, y);
+    y = __builtin_fmaf(z, -0.5f, y);
+    float r = m + y;
+    return __builtin_fmaf(fe, 0.693359375f, r);
+}
+
+__device__ __forceinline__ float kns_sigmoid(float x) { return 1.0f / (1.0f + kns_exp(-x)); }
+
+__device__ __forceinline__ float kns_tanh(float x) {
+    float a = __builtin_fabsf(x);
+    float t = kns_exp(-2.0f * a);
+    float v = (1.0f - t) / (1.0f + t);
+    return __builtin_copysignf(v, x);
+}
+
+// LDS traffic between the lanes of ONE wavefront: DS operations of a wave execute in program order, so only the
+// compiler has to be kept from reordering across this point.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------------------ precision traits
+
+struct PF32 {
+    static constexpr int kPrec = kFp32;
+    static constexpr int KB = 16, EPL = 4, NPB = 1;
+    static constexpr int NBH = 17;  // k-blocks covering the 271 hidden units
+    static constexpr bool kHoldA = false;  // 17 x 4 registers of A fragments would spill: re-read them from LDS
+    static constexpr int kGruWaves = 1;
+    typedef f32x4 frag_t;
+    typedef f32x4 gi_t;
+    typedef float elem_t;
+    static __device__ __forceinline__ f32x4 mma(frag_t a, frag_t b, f32x4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+        return c;
+    }
+    static __device__ __forceinline__ int off(int rc, int kk) { return pack_off_f32(rc, kk); }
+    static __device__ __forceinline__ elem_t cvt(float v) { return v; }
+    static __device__ __forceinline__ gi_t to_gi(f32x4 v) { return v; }
+    static __device__ __forceinline__ f32x4 from_gi(gi_t v) { return v; }
+};
+
+struct PBF16 {
+    static constexpr int kPrec = kBf16;
+    static constexpr int KB = 32, EPL = 8, NPB = 2;
+    static constexpr int NBH = 9;
+    static constexpr bool kHoldA = true;
+    static constexpr int kGruWaves = 1;
+    typedef bf16x8 frag_t;
+    typedef f16x4 gi_t;
+    typedef uint16_t elem_t;
+    static __device__ __forceinline__ f32x4 mma(frag_t a, frag_t b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int off(int rc, int kk) { return pack_off_bf16(rc, kk); }
+    static __device__ __forceinline__ elem_t cvt(float v) { return f2bf(v); }
+    static __device__ __forceinline__ gi_t to_gi(f32x4 v) { return __builtin_convertvector(v, gi_t); }
+    static __device__ __forceinline__ f32x4 from_gi(gi_t v) {
+        f32x4 r;
+        r[0] = (float) v[0];
+        r[1] = (float) v[1];
+        r[2] = (float) v[2];
+        r[3] = (float) v[3];
+        return r;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ FFT-256 per wave
+
+// complex numbers as packed pairs: add/sub are one v_pk_add_f32, a complex multiply is v_pk_mul_f32 + v_pk_fma_f32
+typedef float cpx __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cpx cadd(cpx a, cpx b) { return a + b; }
+__device__ __forceinline__ cpx csub(cpx a, cpx b) { return a - b; }
+__device__ __forceinline__ cpx cmul(cpx a, cpx w) {
+    const cpx t = cpx{a.y, a.y} * cpx{-w.y, w.x};
+    return __builtin_elementwise_fma(cpx{a.x, a.x}, w, t);
+}
+
+__device__ __forceinline__ void radix4(cpx (&v)[4]) {
+    cpx a0 = cadd(v[0], v[2]), a1 = csub(v[0], v[2]), a2 = cadd(v[1], v[3]), d = csub(v[1], v[3]);
+    cpx a3 = {d.y, -d.x};  // (v1 - v3) * (-i)
+    v[0] = cadd(a0, a2);
+    v[1] = cadd(a1, a3);
+    v[2] = csub(a0, a2);
+    v[3] = csub(a1, a3);
+}
+
+// LDS exchange buffers of the wave FFT: two ping-pong arrays of 256 interleaved complex values (ds_read/write_b64
+// straight into the packed register pairs).  Padding them against the 4-way write conflicts of the first two radix-4
+// stages was measured SLOWER on MI355X (synthesis 246 vs 193 us): the extra address VALU costs more than the conflicts.
+constexpr int kFftBufFloats = 4 * 256;  // per wave: 2 buffers x 256 complex
+
+// Forward 256-point complex FFT of one wavefront, radix-4 Stockham autosort.  On entry v[r] = z[lane + 64 r].
+// `buf` is this wave's LDS scratch (kFftBufFloats floats).  On return the spectrum is in natural order in the first
+// buffer (((cpx *) buf)[k]) and visible to the whole wave.  tw = exp(-2 pi i k / 512), k = 0..511, in LDS.
+__device__ __forceinline__ void fft256_wave(cpx (&v)[4], float *buf, const float2 *tw, int lane) {
+    cpx *b0 = (cpx *) buf, *b1 = (cpx *) buf + 256;
+    // stage Ns = 1 (all twiddles are 1)
+    radix4(v);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b1[4 * lane + r] = v[r];
+    wave_lds_sync();
+    // stages Ns = 4, 16, 64
+#pragma unroll
+    for (int s = 1; s < 4; ++s) {
+        const int Ns = 1 << (2 * s);
+        cpx *src = (s & 1) ? b1 : b0;
+        cpx *dst = (s & 1) ? b0 : b1;
+        const int k = lane & (Ns - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = src[lane + 64 * r];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) {
+            float2 w = tw[r * k * (128 / Ns)];
+            v[r] = cmul(v[r], cpx{w.x, w.y});
+        }
+        radix4(v);
+        const int j0 = (lane / Ns) * Ns * 4 + k;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[j0 + r * Ns] = v[r];
+        wave_lds_sync();
+    }
+    // s = 1 -> b0, s = 2 -> b1, s = 3 -> b0: result is in b0
+}
+
+constexpr int kGruTilesPerWave = 5;  // 17 unit tiles over 4 waves: 5,4,4,4
+
+// ---- bf16 recurrent kernel with the layer's W_hh RESIDENT on the CU for all T steps ("persistent RNN"):
+// 459 KiB of B-fragments = 4 waves x 3 unit tiles x 27 blocks in VGPRs (324 registers per lane, one wave per SIMD with
+// the whole 512-register file) + 4 x 27 KiB + 27 KiB in LDS.  Per step a wave then needs only the 16 x 288 bf16 hidden
+// tile from LDS and its 15/12 pre-activation tiles from HBM: no weight traffic at all after the prologue.
+// Gate nonlinearities use the hardware transcendentals (v_exp_f32, v_rcp_f32): the bf16 configuration is specified to a
+// tolerance, not bit for bit.
+
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.88539008177792681f));
+}
+
+constexpr int kResTileBytes = 3 * PBF16::NBH * 1024;  // one unit tile of W_hh: 3 gates x 9 k-blocks x 1 KiB
+constexpr int kResBiasBytes = kGateTiles * 16 * 4;
+constexpr int kResLds = 2 * PBF16::NBH * 1024 + 5 * kResTileBytes + kResBiasBytes;  // h double buffer, 4 + 1 tiles, b_hh
+
+// hipcc keeps values it loaded itself in VGPRs and reaches the accumulator half of the register file only through
+// v_accvgpr copies.  Passing a fragment once through an "a"-constrained empty asm re-defines it as an AGPR value; the
+// MFMA builtins then take it as an AGPR source operand directly, so 216 registers of weights cost no VGPR and no copy.
+__device__ __forceinline__ bf16x8 pin_to_agpr(bf16x8 w) {
+    asm volatile("" : "+a"(w));
+    return w;
+}
+
+// acc[gt] += a[blk] . W for one LDS-resident unit tile stored as [k-block][gate][lane]; the explicit queue keeps
+// kQueue ds_read_b128 in flight so that LDS latency is not paid per MFMA
+template <int NBH, int kQueue>
+__device__ __forceinline__ void mma_lds_tile(f32x4 (&acc)[3], const bf16x8 (&a)[NBH], const bf16x8 *wl, int lane) {
+    constexpr int N = 3 * NBH;
+    bf16x8 qb[kQueue];
+#pragma unroll
+    for (int p = 0; p < kQueue; ++p) qb[p] = wl[p * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);  // pin the order: without it hipcc sinks each read next to its MFMA
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const bf16x8 b = qb[i % kQueue];
+        if (i + kQueue < N) qb[i % kQueue] = wl[(i + kQueue) * 64 + lane];
+        acc[i % 3] = PBF16::mma(a[i / 3], b, acc[i % 3]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 fast_sigmoid2(f32x2 x) {
+    f32x2 e = x * f32x2{-1.44269504088896341f, -1.44269504088896341f};
+    e = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + f32x2{1.0f, 1.0f};
+    return f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+}
+__device__ __forceinline__ f32x2 fast_tanh2(f32x2 x) {
+    f32x2 e = x * f32x2{2.88539008177792681f, 2.88539008177792681f};
+    e = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + f32x2{1.0f, 1.0f};
+    f32x2 r = f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+    return f32x2{1.0f, 1.0f} - (r + r);
+}
+
+}  // namespace kns

@@ -1,0 +1,629 @@
+// kns_gemm.hip -- every GEMM over stream-frames: generic, weight-stationary input GEMMs, narrow GEMMs, heads.
+#include "kns_device.hpp"
+
+namespace kns {
+
+// ------------------------------------------------------------------------------------------------ GEMM
+
+constexpr int kGemmMT = 4;  // m-tiles (of 16 stream-frames) per workgroup
+constexpr int kPF = 4;      // weight prefetch depth in k-blocks
+
+template <class P, int OUT>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename P::frag_t frag_t;
+    constexpr bool kApack = (OUT == kOutAPlain || OUT == kOutASigmoid);
+    constexpr bool kSigmoid = (OUT == kOutMask || OUT == kOutASigmoid);
+    constexpr int NU = kApack ? P::NPB : 1;  // n-tiles per unit of work
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = g.nb0 + g.nb1;
+    const int mt0 = blockIdx.x * kGemmMT;
+    const int mcount = min(kGemmMT, g.mtiles - mt0);
+
+    // stage the A tile in LDS, keeping fragment order: [m-tile][k-block][lane] 16-byte words
+    uint4 *lds_a = (uint4 *) smem;
+    for (int m = 0; m < mcount; ++m) {
+        if (g.nb0) {
+            const uint4 *src = (const uint4 *) g.a0 + (size_t) (mt0 + m) * g.nb0 * 64;
+            for (int i = tid; i < g.nb0 * 64; i += 256) lds_a[m * nb * 64 + i] = src[i];
+        }
+        const uint4 *src1 = (const uint4 *) g.a1 + (size_t) (mt0 + m) * g.nb1 * 64;
+        for (int i = tid; i < g.nb1 * 64; i += 256) lds_a[(m * nb + g.nb0) * 64 + i] = src1[i];
+    }
+    for (int m = mcount; m < kGemmMT; ++m)
+        for (int i = tid; i < nb * 64; i += 256) lds_a[m * nb * 64 + i] = uint4{0, 0, 0, 0};
+    __syncthreads();
+
+    const frag_t *lds_f = (const frag_t *) smem;
+    char *scratch = smem + (size_t) kGemmMT * nb * 1024 + (size_t) wave * kGemmMT * 1024;  // per-wave transposer
+
+    const int units = g.ntiles / NU;
+    const int units_per_y = ceil_div(units, (int) gridDim.y);
+    const int u_begin = blockIdx.y * units_per_y;
+    const int u_end = min(units, u_begin + units_per_y);
+    const frag_t *w = (const frag_t *) g.w;
+
+    for (int u = u_begin + wave; u < u_end; u += 4) {
+        const int nt0 = u * NU;
+        f32x4 acc[NU][kGemmMT];
+#pragma unroll
+        for (int j = 0; j < NU; ++j)
+#pragma unroll
+            for (int m = 0; m < kGemmMT; ++m) acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        frag_t bq[kPF][NU];
+#pragma unroll
+        for (int p = 0; p < kPF; ++p)
+            if (p < nb)
+#pragma unroll
+                for (int j = 0; j < NU; ++j) bq[p][j] = w[((size_t) (nt0 + j) * nb + p) * 64 + lane];
+        for (int blk0 = 0; blk0 < nb; blk0 += kPF) {
+#pragma unroll
+            for (int p = 0; p < kPF; ++p) {
+                const int blk = blk0 + p;
+                if (blk < nb) {
+                    frag_t bc[NU];
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) bc[j] = bq[p][j];
+                    if (blk + kPF < nb)
+#pragma unroll
+                        for (int j = 0; j < NU; ++j) bq[p][j] = w[((size_t) (nt0 + j) * nb + blk + kPF) * 64 + lane];
+#pragma unroll
+                    for (int m = 0; m < kGemmMT; ++m) {
+                        frag_t a = lds_f[(m * nb + blk) * 64 + lane];
+#pragma unroll
+                        for (int j = 0; j < NU; ++j) acc[j][m] = P::mma(a, bc[j], acc[j][m]);
+                    }
+                }
+            }
+        }
+
+        // epilogue: lane owns column (lane & 15) of each n-tile, rows (lane >> 4) * 4 + i
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            const int nt = nt0 + j;
+            const int col = nt * 16 + (lane & 15);
+            const float bias = g.bias[col];
+#pragma unroll
+            for (int m = 0; m < kGemmMT; ++m) {
+                f32x4 v = acc[j][m];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float x = v[i] + bias;
+                    if (kSigmoid) x = kns_sigmoid(x);
+                    if (kApack && col >= g.n_valid) x = 0.0f;
+                    v[i] = x;
+                }
+                if (!kApack) {
+                    if (m < mcount) {
+                        const size_t idx = ((size_t) (mt0 + m) * g.ntiles + nt) * 64 + lane;
+                        if (OUT == kOutGi)
+                            ((typename P::gi_t *) g.out)[idx] = P::to_gi(v);
+                        else
+                            ((f32x4 *) g.out)[idx] = v;
+                    }
+                } else {
+                    typename P::elem_t *sc = (typename P::elem_t *) (scratch + m * 1024);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sc[P::off((lane >> 4) * 4 + i, j * 16 + (lane & 15))] = P::cvt(v[i]);
+                }
+            }
+        }
+        if (kApack) {
+            wave_lds_sync();
+            const int out_nb = g.ntiles / NU;
+            for (int m = 0; m < mcount; ++m) {
+                uint4 word = ((const uint4 *) (scratch + m * 1024))[lane];
+                ((uint4 *) g.out)[((size_t) (mt0 + m) * out_nb + u) * 64 + lane] = word;
+            }
+            wave_lds_sync();
+        }
+    }
+}
+
+// ---- weight-stationary form of the GRU input-side GEMM (bf16):  Gi = [y_prev ; e] . W_ih + b_ih  over ALL stream-frames.
+// The 51 x 9 e-part blocks of W_ih stay on the CU exactly as W_hh does in gru_resident_kernel (VGPR / AGPR / LDS per
+// wave); the y_prev part (0..2 k-blocks) is re-read from L2 per m-tile.  A persistent workgroup walks over m-tiles:
+// A fragments come straight from HBM in fragment order (no LDS, no barrier), C tiles leave as fp16 fragments.
+// HBM traffic per m-tile is the algorithmic minimum: 9-11 KiB in, 25.5 KiB out.
+constexpr int kWsABlocks = PBF16::NBH + 2;                               // k-blocks of one A tile (y part <= 2)
+constexpr int kWsLds = 5 * kResTileBytes + 2 * kWsABlocks * 1024;        // weight tiles 3, 4 + A double buffer
+
+template <int NB0>
+__global__ __launch_bounds__(256, 1) void gemm_ws_kernel(GemmArgs g) {
+    typedef PBF16 P;
+    typedef P::frag_t frag_t;
+    constexpr int NBH = P::NBH;
+    __shared__ __attribute__((aligned(16))) char smem[kWsLds];
+    frag_t *abuf = (frag_t *) (smem + 5 * kResTileBytes);  // [2][kWsABlocks][64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int colq = lane & 15;
+    constexpr int nb0 = NB0, nb = NB0 + NBH;
+    const frag_t *w = (const frag_t *) g.w;
+
+    frag_t wv[3][NBH];
+    frag_t wa[2][3][NBH];
+#pragma unroll
+    for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+        for (int blk = 0; blk < NBH; ++blk) wv[gt][blk] = w[((size_t) (wave * 3 + gt) * nb + nb0 + blk) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+            for (int blk = 0; blk < NBH; ++blk) {
+                wa[q][gt][blk] = pin_to_agpr(w[((size_t) ((wave + 4 * (q + 1)) * 3 + gt) * nb + nb0 + blk) * 64 + lane]);
+            }
+    frag_t *wl3 = (frag_t *) (smem + wave * kResTileBytes);
+    frag_t *wl4 = (frag_t *) (smem + 4 * kResTileBytes);
+    for (int gt = 0; gt < 3; ++gt)
+        for (int blk = 0; blk < NBH; ++blk)
+            wl3[(blk * 3 + gt) * 64 + lane] = w[((size_t) ((wave + 12) * 3 + gt) * nb + nb0 + blk) * 64 + lane];
+    if (wave == 0)
+        for (int gt = 0; gt < 3; ++gt)
+            for (int blk = 0; blk < NBH; ++blk)
+                wl4[(blk * 3 + gt) * 64 + lane] = w[((size_t) (16 * 3 + gt) * nb + nb0 + blk) * 64 + lane];
+    float bias[kGruTilesPerWave][3];
+#pragma unroll
+    for (int q = 0; q < kGruTilesPerWave; ++q)
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt) {
+            const int u = wave + 4 * q;
+            bias[q][gt] = u < kUnitTiles ? g.bias[(u * 3 + gt) * 16 + colq] : 0.0f;
+        }
+
+    // A tile staging: block j of an m-tile (j < nb0: y part, else e part) is fetched by wave j & 3
+    const frag_t *a0p = (const frag_t *) g.a0;
+    const frag_t *a1p = (const frag_t *) g.a1;
+    auto fetch = [&](int mtile, int j) -> frag_t {
+        return j < nb0 ? a0p[((size_t) mtile * nb0 + j) * 64 + lane] : a1p[((size_t) mtile * NBH + (j - nb0)) * 64 + lane];
+    };
+    int mt = blockIdx.x;
+    if (mt < g.mtiles)
+        for (int j = wave; j < nb; j += 4) abuf[j * 64 + lane] = fetch(mt, j);
+    __syncthreads();
+
+    int cur = 0;
+    for (; mt < g.mtiles; mt += gridDim.x) {
+        const int mn = mt + gridDim.x;
+        frag_t stage[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int j = wave + 4 * i;
+            if (mn < g.mtiles && j < nb) stage[i] = fetch(mn, j);  // in flight during this tile's MFMAs
+        }
+        const frag_t *ab = abuf + cur * kWsABlocks * 64;
+        frag_t cy[NB0 > 0 ? NB0 : 1], ce[NBH];
+#pragma unroll
+        for (int blk = 0; blk < NB0; ++blk) cy[blk] = ab[blk * 64 + lane];
+#pragma unroll
+        for (int blk = 0; blk < NBH; ++blk) ce[blk] = ab[(nb0 + blk) * 64 + lane];
+        P::gi_t *out = (P::gi_t *) g.out + (size_t) mt * kGateTiles * 64;
+#pragma unroll
+        for (int q = 0; q < kGruTilesPerWave; ++q) {
+            const int u = wave + 4 * q;
+            {
+                f32x4 acc[3];
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (NB0 > 0) {
+                    frag_t wy[NB0 > 0 ? NB0 : 1][3];
+                    __builtin_amdgcn_sched_barrier(0);  // keep the streamed y-part loads of other tiles out of here
+#pragma unroll
+                    for (int blk = 0; blk < NB0; ++blk)
+#pragma unroll
+                        for (int gt = 0; gt < 3; ++gt)
+                            wy[blk][gt] = w[((size_t) ((u < kUnitTiles ? u : 0) * 3 + gt) * nb + blk) * 64 + lane];
+#pragma unroll
+                    for (int blk = 0; blk < NB0; ++blk)
+#pragma unroll
+                        for (int gt = 0; gt < 3; ++gt) acc[gt] = P::mma(cy[blk], wy[blk][gt], acc[gt]);
+                }
+                if (q < 3) {
+#pragma unroll
+                    for (int blk = 0; blk < NBH; ++blk)
+#pragma unroll
+                        for (int gt = 0; gt < 3; ++gt)
+                            acc[gt] = P::mma(ce[blk], q == 0 ? wv[gt][blk] : wa[q == 2 ? 1 : 0][gt][blk], acc[gt]);
+                } else {
+                    mma_lds_tile<NBH, 4>(acc, ce, q == 3 ? wl3 : wl4, lane);
+                }
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt) {
+                    f32x4 v = acc[gt];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[q][gt];
+                    if (q < 4 || wave == 0) out[(u * 3 + gt) * 64 + lane] = P::to_gi(v);
+                }
+            }
+        }
+        frag_t *an = abuf + (cur ^ 1) * kWsABlocks * 64;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int j = wave + 4 * i;
+            if (mn < g.mtiles && j < nb) an[j * 64 + lane] = stage[i];
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// ---- second form of the weight-stationary input GEMM: the 51 n-tiles are split over a PAIR of workgroups that sit on
+// the same XCD (blocks g and g + 8), so one wave keeps at most 7 n-tiles x (9 + NB0) k-blocks = 77 fragments -- all of
+// them in registers (3 n-tiles in VGPRs, 4 pinned in AGPRs), including the y_prev part.  No weight ever comes from LDS
+// or L2 inside the loop; LDS only double-buffers A tiles, kWs2Stage m-tiles per barrier.  The partner's second read of
+// an A tile hits the XCD's L2.
+constexpr int kWs2Waves = 8;    // two waves per SIMD: one wave's MFMAs run under the other's epilogue VALU
+constexpr int kWs2Tiles = 4;    // n-tiles per wave (the 4th only on some waves): 26 / 8 -> 4,4,3,...
+
+template <int NB0, int kWs2Stage>  // kWs2Stage: m-tiles staged per barrier
+__global__ __launch_bounds__(64 * kWs2Waves, 2) void gemm_ws2_kernel(GemmArgs g) {
+    typedef PBF16 P;
+    typedef P::frag_t frag_t;
+    constexpr int NB = P::NBH + NB0;
+    __shared__ __attribute__((aligned(16))) char smem[2 * kWs2Stage * NB * 1024];
+    frag_t *abuf = (frag_t *) smem;  // [2][kWs2Stage][NB][64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int colq = lane & 15;
+    const int bid = blockIdx.x;
+    const int half = (bid >> 3) & 1;
+    const int mgroup = (bid >> 4) * 8 + (bid & 7);      // 0 .. gridDim.x / 2 - 1
+    const int mstride = (gridDim.x >> 1) * kWs2Stage;   // m-tiles between consecutive stages of this workgroup
+    const int nt_base = half ? 26 : 0, nt_count = half ? kGateTiles - 26 : 26;
+    const frag_t *w = (const frag_t *) g.w;
+
+    // this wave's n-tiles: nt_base + wave + 8 j; j < 3 always exists, j = 3 only on the first waves of a half
+    int nt[kWs2Tiles];
+#pragma unroll
+    for (int j = 0; j < kWs2Tiles; ++j) nt[j] = nt_base + (wave + kWs2Waves * j < nt_count ? wave + kWs2Waves * j : 0);
+    const bool has4 = wave + kWs2Waves * 3 < nt_count;
+    frag_t wr[kWs2Tiles][NB];
+    float bias[kWs2Tiles];
+#pragma unroll
+    for (int j = 0; j < kWs2Tiles; ++j) {
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) wr[j][blk] = w[((size_t) nt[j] * NB + blk) * 64 + lane];
+        bias[j] = g.bias[nt[j] * 16 + colq];
+    }
+
+    // A staging: block i of a stage (i = m * NB + blk; blk < NB0 is the y part) is fetched by wave i % 8.
+    // The launch guarantees mtiles % (kWs2Stage * gridDim.x / 2) == 0, so every staged m-tile exists.
+    constexpr int kStageBlocks = kWs2Stage * NB;
+    constexpr int kFetch = (kStageBlocks + kWs2Waves - 1) / kWs2Waves;
+    const frag_t *src[kFetch];
+    size_t step[kFetch];
+#pragma unroll
+    for (int i = 0; i < kFetch; ++i) {
+        const int idx = wave + kWs2Waves * i;
+        const int m = idx / NB, blk = idx % NB;
+        const int mt = mgroup * kWs2Stage + m;
+        if (blk < NB0) {
+            src[i] = (const frag_t *) g.a0 + ((size_t) mt * NB0 + blk) * 64 + lane;
+            step[i] = (size_t) mstride * NB0 * 64;
+        } else {
+            src[i] = (const frag_t *) g.a1 + ((size_t) mt * P::NBH + (blk - NB0)) * 64 + lane;
+            step[i] = (size_t) mstride * P::NBH * 64;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kFetch; ++i)
+        if (wave + kWs2Waves * i < kStageBlocks) abuf[(wave + kWs2Waves * i) * 64 + lane] = *src[i];
+    __syncthreads();
+
+    auto store_tile = [&](P::gi_t *out, int j, f32x4 v) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[j];
+        out[nt[j] * 64 + lane] = P::to_gi(v);
+    };
+
+    int cur = 0;
+    for (int mt0 = mgroup * kWs2Stage; mt0 < g.mtiles; mt0 += mstride) {
+        const bool more = mt0 + mstride < g.mtiles;
+        frag_t stage[kFetch];
+#pragma unroll
+        for (int i = 0; i < kFetch; ++i) {
+            src[i] += step[i];
+            if (more && wave + kWs2Waves * i < kStageBlocks) stage[i] = *src[i];  // in flight during this stage's MFMAs
+        }
+#pragma unroll
+        for (int m = 0; m < kWs2Stage; ++m) {
+            const frag_t *ab = abuf + (cur * kStageBlocks + m * NB) * 64;
+            P::gi_t *out = (P::gi_t *) g.out + (size_t) (mt0 + m) * kGateTiles * 64;
+            // three independent accumulator chains over the always-present n-tiles; A fragments streamed from LDS
+            f32x4 acc[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 acc3 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                const frag_t a = ab[blk * 64 + lane];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[c] = P::mma(a, wr[c][blk], acc[c]);
+                if (has4) acc3 = P::mma(a, wr[3][blk], acc3);
+            }
+            if (m == kWs2Stage - 1) {
+                // hand the next stage's A tiles to LDS before this m-tile's stores are issued: vmcnt counts stores too on
+                // gfx950, so a wait placed after them would also wait for their write acknowledgements
+#pragma unroll
+                for (int i = 0; i < kFetch; ++i)
+                    if (more && wave + kWs2Waves * i < kStageBlocks)
+                        abuf[((cur ^ 1) * kStageBlocks + wave + kWs2Waves * i) * 64 + lane] = stage[i];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) store_tile(out, c, acc[c]);
+            if (has4) store_tile(out, 3, acc3);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// ---- weight-stationary form of the narrow GEMMs (front-end 257->271, heads 271->{1,5,40,257}; bf16): 8 waves per
+// workgroup, every wave keeps its n-tiles' 9 k-blocks in VGPRs (at most 36 fragments), a persistent workgroup walks
+// m-tiles with the A tile double-buffered in LDS.  These GEMMs are bound by streaming A in and the result out.
+constexpr int kWsrStage = 2;
+
+template <int OUT, int UW>  // UW: units (pairs of n-tiles for A-packed outputs, single n-tiles for the mask) per wave
+__global__ __launch_bounds__(512, 2) void gemm_wsr_kernel(GemmArgs g) {
+    typedef PBF16 P;
+    typedef P::frag_t frag_t;
+    constexpr int NB = P::NBH;  // both the feature tile (257 -> 288) and a hidden tile (271 -> 288) are 9 k-blocks
+    constexpr bool kApack = (OUT == kOutAPlain || OUT == kOutASigmoid);
+    constexpr bool kSigmoid = (OUT == kOutMask || OUT == kOutASigmoid);
+    constexpr int NU = kApack ? P::NPB : 1;
+    __shared__ __attribute__((aligned(16))) char smem[2 * kWsrStage * NB * 1024 + 8 * 1024];
+    frag_t *abuf = (frag_t *) smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char *scratch = smem + 2 * kWsrStage * NB * 1024 + wave * 1024;  // per-wave transposer for A-packed outputs
+    const int colq = lane & 15;
+    const int units = g.ntiles / NU;
+    const frag_t *w = (const frag_t *) g.w;
+
+    int unit[UW];
+    bool live[UW];
+    frag_t wr[UW * NU][NB];
+    float bias[UW * NU];
+#pragma unroll
+    for (int q = 0; q < UW; ++q) {
+        live[q] = wave + 8 * q < units;
+        unit[q] = live[q] ? wave + 8 * q : 0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            const int nt = unit[q] * NU + j;
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) wr[q * NU + j][blk] = w[((size_t) nt * NB + blk) * 64 + lane];
+            bias[q * NU + j] = g.bias[nt * 16 + colq];
+        }
+    }
+
+    constexpr int kStageBlocks = kWsrStage * NB;
+    constexpr int kFetch = (kStageBlocks + 7) / 8;
+    const int mstride = gridDim.x * kWsrStage;
+    const frag_t *a1p = (const frag_t *) g.a1;
+    int mt0 = blockIdx.x * kWsrStage;
+    for (int i = wave; i < kStageBlocks; i += 8)
+        if (mt0 + i / NB < g.mtiles) abuf[i * 64 + lane] = a1p[((size_t) mt0 * NB + i) * 64 + lane];
+    __syncthreads();
+
+    int cur = 0;
+    for (; mt0 < g.mtiles; mt0 += mstride) {
+        const int mn = mt0 + mstride;
+        frag_t stage[kFetch];
+#pragma unroll
+        for (int i = 0; i < kFetch; ++i) {
+            const int idx = wave + 8 * i;
+            if (idx < kStageBlocks && mn + idx / NB < g.mtiles) stage[i] = a1p[((size_t) mn * NB + idx) * 64 + lane];
+        }
+        if (live[0]) {
+#pragma unroll
+            for (int m = 0; m < kWsrStage; ++m) {
+                const int mt = mt0 + m;
+                if (mt < g.mtiles) {
+                    const frag_t *ab = abuf + (cur * kStageBlocks + m * NB) * 64;
+                    frag_t a[NB];
+#pragma unroll
+                    for (int blk = 0; blk < NB; ++blk) a[blk] = ab[blk * 64 + lane];
+#pragma unroll
+                    for (int q = 0; q < UW; ++q) {
+                        if (live[q]) {
+                            f32x4 acc[NU];
+#pragma unroll
+                            for (int j = 0; j < NU; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+                                for (int j = 0; j < NU; ++j) acc[j] = P::mma(a[blk], wr[q * NU + j][blk], acc[j]);
+#pragma unroll
+                            for (int j = 0; j < NU; ++j) {
+                                const int nt = unit[q] * NU + j;
+                                f32x4 v = acc[j];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    float x = v[i] + bias[q * NU + j];
+                                    if (kSigmoid) x = kns_sigmoid(x);
+                                    if (kApack && nt * 16 + colq >= g.n_valid) x = 0.0f;
+                                    v[i] = x;
+                                }
+                                if (!kApack) {
+                                    ((f32x4 *) g.out)[((size_t) mt * g.ntiles + nt) * 64 + lane] = v;
+                                } else {
+                                    uint16_t *sc = (uint16_t *) scratch;
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i)
+                                        sc[P::off((lane >> 4) * 4 + i, j * 16 + colq)] = P::cvt(v[i]);
+                                }
+                            }
+                            if (kApack) {
+                                wave_lds_sync();
+                                ((uint4 *) g.out)[((size_t) mt * units + unit[q]) * 64 + lane] = ((const uint4 *) scratch)[lane];
+                                wave_lds_sync();
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        frag_t *an = abuf + (cur ^ 1) * kStageBlocks * 64;
+#pragma unroll
+        for (int i = 0; i < kFetch; ++i) {
+            const int idx = wave + 8 * i;
+            if (idx < kStageBlocks && mn + idx / NB < g.mtiles) an[idx * 64 + lane] = stage[i];
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// ---- narrow heads (271 -> 1, 5, 40; bf16): the whole weight image is only 2-4 n-tiles, so every wave keeps ALL of it
+// in registers and the waves split the m-tiles instead of the n-tiles: no LDS staging, no barrier, A fragments
+// double-buffered in registers straight from HBM.  (With the n-tiles split over waves one or two waves did all the
+// sigmoids of a workgroup and the kernel was VALU-bound at 36 us; this form is bound by reading A.)
+template <int NT>  // n-tiles (2 or 4)
+__global__ __launch_bounds__(512, 2) void gemm_head_kernel(GemmArgs g) {
+    typedef PBF16 P;
+    typedef P::frag_t frag_t;
+    constexpr int NB = P::NBH;
+    __shared__ __attribute__((aligned(16))) char smem[8 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint16_t *sc = (uint16_t *) (smem + wave * 1024);  // this wave's transposer: C-fragments -> one A-packed block
+    const int colq = lane & 15;
+    const frag_t *w = (const frag_t *) g.w;
+    frag_t wr[NT][NB];
+    float bias[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) wr[j][blk] = w[((size_t) j * NB + blk) * 64 + lane];
+        bias[j] = g.bias[j * 16 + colq];
+    }
+    const frag_t *a1p = (const frag_t *) g.a1;
+    const int stride = gridDim.x * 8;
+    int mt = blockIdx.x * 8 + wave;
+    frag_t an[NB];
+    if (mt < g.mtiles) {
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) an[blk] = a1p[((size_t) mt * NB + blk) * 64 + lane];
+    }
+    for (; mt < g.mtiles; mt += stride) {
+        frag_t a[NB];
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) a[blk] = an[blk];
+        if (mt + stride < g.mtiles) {
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) an[blk] = a1p[((size_t) (mt + stride) * NB + blk) * 64 + lane];
+        }
+#pragma unroll
+        for (int pair = 0; pair < NT / 2; ++pair) {
+            f32x4 acc[2];
+            acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = P::mma(a[blk], wr[pair * 2 + j][blk], acc[j]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nt = pair * 2 + j;
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (nt * 16 < g.n_valid) {  // an n-tile made of padding columns only needs no sigmoid
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float x = kns_sigmoid(acc[j][i] + bias[nt]);
+                        v[i] = nt * 16 + colq < g.n_valid ? x : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sc[P::off((lane >> 4) * 4 + i, j * 16 + colq)] = P::cvt(v[i]);
+            }
+            wave_lds_sync();
+            ((uint4 *) g.out)[((size_t) mt * (NT / 2) + pair) * 64 + lane] = ((const uint4 *) sc)[lane];
+            wave_lds_sync();
+        }
+    }
+}
+
+template <class P>
+static void launch_gemm_p(const GemmArgs &a, hipStream_t s) {
+    const int nb = a.nb0 + a.nb1;
+    const int gx = ceil_div(a.mtiles, kGemmMT);
+    const bool apack = a.out_kind == kOutAPlain || a.out_kind == kOutASigmoid;
+    const int units = a.ntiles / (apack ? P::NPB : 1);
+    // few stream-frames: split the n-tiles over more workgroups so the weight stream is spread over the CUs
+    int gy = 1;
+    if (gx < 256) gy = min(ceil_div(units, 4), max(1, 512 / gx));
+    size_t lds = (size_t) kGemmMT * nb * 1024 + 4 * kGemmMT * 1024;
+    dim3 grid(gx, gy);
+    switch (a.out_kind) {
+        case kOutGi: hipLaunchKernelGGL((gemm_kernel<P, kOutGi>), grid, dim3(256), lds, s, a); break;
+        case kOutMask: hipLaunchKernelGGL((gemm_kernel<P, kOutMask>), grid, dim3(256), lds, s, a); break;
+        case kOutAPlain: hipLaunchKernelGGL((gemm_kernel<P, kOutAPlain>), grid, dim3(256), lds, s, a); break;
+        default: hipLaunchKernelGGL((gemm_kernel<P, kOutASigmoid>), grid, dim3(256), lds, s, a); break;
+    }
+}
+
+void launch_gemm(const GemmArgs &a, hipStream_t s) {
+    static const bool no_ws = getenv("KOALA_AMD_GEMM_GENERIC") != nullptr;  // A/B switch for profiling
+    if (a.precision == kBf16 && a.out_kind == kOutGi && a.ntiles == kGateTiles && a.nb1 == PBF16::NBH && a.nb0 <= 2 &&
+        a.mtiles >= 256 && !no_ws) {
+        static const bool ws1 = getenv("KOALA_AMD_GEMM_WS1") != nullptr;  // A/B switch: first weight-stationary form
+        const dim3 grid(256), block(64 * kWs2Waves);
+        if (ws1 || a.mtiles % 256 != 0) {
+            if (a.nb0 == 0)
+                hipLaunchKernelGGL(gemm_ws_kernel<0>, dim3(256), dim3(256), 0, s, a);
+            else if (a.nb0 == 1)
+                hipLaunchKernelGGL(gemm_ws_kernel<1>, dim3(256), dim3(256), 0, s, a);
+            else
+                hipLaunchKernelGGL(gemm_ws_kernel<2>, dim3(256), dim3(256), 0, s, a);
+        } else if (a.mtiles % 512 == 0 && a.nb0 < 2) {  // four m-tiles per barrier (NB0 = 2 would spill)
+            if (a.nb0 == 0)
+                hipLaunchKernelGGL((gemm_ws2_kernel<0, 4>), grid, block, 0, s, a);
+            else
+                hipLaunchKernelGGL((gemm_ws2_kernel<1, 4>), grid, block, 0, s, a);
+        } else {
+            if (a.nb0 == 0)
+                hipLaunchKernelGGL((gemm_ws2_kernel<0, 2>), grid, block, 0, s, a);
+            else if (a.nb0 == 1)
+                hipLaunchKernelGGL((gemm_ws2_kernel<1, 2>), grid, block, 0, s, a);
+            else
+                hipLaunchKernelGGL((gemm_ws2_kernel<2, 2>), grid, block, 0, s, a);
+        }
+        return;
+    }
+    static const bool no_wsr = getenv("KOALA_AMD_GEMM_NO_WSR") != nullptr;  // A/B switch
+    if (a.precision == kBf16 && a.nb0 == 0 && a.nb1 == PBF16::NBH && a.mtiles >= 512 && !no_wsr) {
+        const dim3 grid(256), block(512);
+        if (a.out_kind == kOutAPlain && a.ntiles <= 32) {
+            hipLaunchKernelGGL((gemm_wsr_kernel<kOutAPlain, 2>), grid, block, 0, s, a);
+            return;
+        }
+        if (a.out_kind == kOutASigmoid && a.ntiles == 2) {
+            hipLaunchKernelGGL(gemm_head_kernel<2>, grid, block, 0, s, a);
+            return;
+        }
+        if (a.out_kind == kOutASigmoid && a.ntiles == 4) {
+            hipLaunchKernelGGL(gemm_head_kernel<4>, grid, block, 0, s, a);
+            return;
+        }
+        if (a.out_kind == kOutASigmoid && a.ntiles <= 16) {
+            hipLaunchKernelGGL((gemm_wsr_kernel<kOutASigmoid, 1>), grid, block, 0, s, a);
+            return;
+        }
+        if (a.out_kind == kOutMask && a.ntiles <= 24) {
+            hipLaunchKernelGGL((gemm_wsr_kernel<kOutMask, 3>), grid, block, 0, s, a);
+            return;
+        }
+    }
+    if (a.precision == kBf16)
+        launch_gemm_p<PBF16>(a, s);
+    else
+        launch_gemm_p<PF32>(a, s);
+}
+
+}  // namespace kns

@@ -1,0 +1,594 @@
+// kns_gru.hip -- recurrent halves of the GRU layers: streaming, resident (4 and 8 waves), low-latency.
+#include "kns_device.hpp"
+
+namespace kns {
+
+// ------------------------------------------------------------------------------------------------ recurrent GRU
+
+// Weights streamed from L2 every step (fp32 parity path; bf16 only as an A/B switch).  W waves per workgroup share the
+// 17 unit tiles round-robin; the B fragments of a tile are fetched two k-blocks (six fragments) ahead of their MFMAs, and with W = 8 two waves per SIMD cover each other's latencies.
+template <class P, int W>
+__global__ __launch_bounds__(64 * W, W / 4) void gru_kernel(GruArgs g) {
+    typedef typename P::frag_t frag_t;
+    typedef typename P::elem_t elem_t;
+    constexpr int NBH = P::NBH;
+    constexpr int TPW = (kUnitTiles + W - 1) / W;  // unit tiles per wave
+    __shared__ __attribute__((aligned(16))) char hbuf[2][NBH * 1024];  // operand-typed hidden state, A-packed
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = blockIdx.x;
+    const int colq = lane & 15, rowq = (lane >> 4) * 4;
+
+    // fp32 hidden state of the (row, unit) elements this lane owns
+    f32x4 hreg[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int u = wave + W * q;
+        hreg[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (u < kUnitTiles) hreg[q] = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u) * 64 + lane];
+    }
+    for (int i = tid; i < 2 * NBH * 64; i += 64 * W) ((uint4 *) hbuf)[i] = uint4{0, 0, 0, 0};
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int u = wave + W * q;
+        if (u < kUnitTiles) {
+            const int k = u * 16 + colq;
+            elem_t *dst = (elem_t *) hbuf[0] + (k / P::KB) * 64 * P::EPL;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[P::off(rowq + i, k % P::KB)] = P::cvt(hreg[q][i]);
+        }
+    }
+    __syncthreads();
+
+    const frag_t *whh = (const frag_t *) g.whh;
+    int cur = 0;
+    for (int t = 0; t < g.T; ++t) {
+        const frag_t *ha = (const frag_t *) hbuf[cur];
+        if (t > 0) {  // what is in LDS now is h_{t-1}: publish it as the next layer's A operand
+            frag_t *hs = (frag_t *) g.hseq + ((size_t) (t - 1) * g.mtiles + mt) * NBH * 64;
+            for (int blk = wave; blk < NBH; blk += W) hs[blk * 64 + lane] = ha[blk * 64 + lane];
+        }
+        const typename P::gi_t *gi = (const typename P::gi_t *) g.gi + ((size_t) t * g.mtiles + mt) * kGateTiles * 64;
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+            const int u = wave + W * q;
+            if (u < kUnitTiles) {
+                typename P::gi_t gir = gi[(u * 3 + 0) * 64 + lane];
+                typename P::gi_t giz = gi[(u * 3 + 1) * 64 + lane];
+                typename P::gi_t gin = gi[(u * 3 + 2) * 64 + lane];
+                f32x4 acc[3];
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // B fragments two k-blocks ahead of their MFMAs, rotated through registers (a rolled loop: unrolling all 51
+                // fp32 k-block/gate pairs makes hipcc materialise an address pair per load and spill)
+                const frag_t *wu = whh + (size_t) u * 3 * NBH * 64 + lane;
+                frag_t b0[3], b1[3], b2[3];
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt) {
+                    b0[gt] = wu[(gt * NBH + 0) * 64];
+                    b1[gt] = wu[(gt * NBH + 1) * 64];
+                    b2[gt] = wu[(gt * NBH + 2) * 64];
+                }
+#pragma nounroll
+                for (int blk = 0; blk < NBH; ++blk) {
+                    const frag_t ab = ha[blk * 64 + lane];
+                    frag_t bc[3];
+#pragma unroll
+                    for (int gt = 0; gt < 3; ++gt) {
+                        bc[gt] = b0[gt];
+                        b0[gt] = b1[gt];
+                        b1[gt] = b2[gt];
+                    }
+                    const int nb = blk + 3 < NBH ? blk + 3 : NBH - 1;
+#pragma unroll
+                    for (int gt = 0; gt < 3; ++gt) b2[gt] = wu[(gt * NBH + nb) * 64];
+#pragma unroll
+                    for (int gt = 0; gt < 3; ++gt) acc[gt] = P::mma(ab, bc[gt], acc[gt]);
+                }
+                const float br = g.bhh[(u * 3 + 0) * 16 + colq];
+                const float bz = g.bhh[(u * 3 + 1) * 16 + colq];
+                const float bn = g.bhh[(u * 3 + 2) * 16 + colq];
+                f32x4 ir = P::from_gi(gir), iz = P::from_gi(giz), in = P::from_gi(gin);
+                const int k = u * 16 + colq;
+                elem_t *dst = (elem_t *) hbuf[cur ^ 1] + (k / P::KB) * 64 * P::EPL;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float r = kns_sigmoid(ir[i] + (acc[0][i] + br));
+                    float z = kns_sigmoid(iz[i] + (acc[1][i] + bz));
+                    float n = kns_tanh(__builtin_fmaf(r, acc[2][i] + bn, in[i]));
+                    float h = __builtin_fmaf(z, hreg[q][i] - n, n);
+                    hreg[q][i] = h;
+                    dst[P::off(rowq + i, k % P::KB)] = P::cvt(h);
+                }
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    {
+        frag_t *hs = (frag_t *) g.hseq + ((size_t) (g.T - 1) * g.mtiles + mt) * NBH * 64;
+        for (int blk = wave; blk < NBH; blk += W) hs[blk * 64 + lane] = ((const frag_t *) hbuf[cur])[blk * 64 + lane];
+    }
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int u = wave + W * q;
+        if (u < kUnitTiles) ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u) * 64 + lane] = hreg[q];
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void gru_resident_kernel(GruArgs g) {
+    typedef PBF16 P;
+    typedef P::frag_t frag_t;
+    constexpr int NBH = P::NBH;
+    __shared__ __attribute__((aligned(16))) char smem[kResLds];
+    char *hbuf0 = smem, *hbuf1 = smem + NBH * 1024;
+    char *wl = smem + 2 * NBH * 1024;
+    float *lbias = (float *) (smem + 2 * NBH * 1024 + 5 * kResTileBytes);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = blockIdx.x;
+    const int colq = lane & 15, rowq = (lane >> 4) * 4;
+    const frag_t *whh = (const frag_t *) g.whh;
+
+    // ---- prologue: this wave's 5 (4) unit tiles of W_hh -> VGPRs (tile 0), AGPRs (tiles 1, 2), LDS (tiles 3, 4)
+    frag_t wv[3][NBH];
+    frag_t wa[2][3][NBH];
+#pragma unroll
+    for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+        for (int blk = 0; blk < NBH; ++blk) wv[gt][blk] = whh[((size_t) (wave * 3 + gt) * NBH + blk) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+            for (int blk = 0; blk < NBH; ++blk) {
+                wa[q][gt][blk] = pin_to_agpr(whh[((size_t) ((wave + 4 * (q + 1)) * 3 + gt) * NBH + blk) * 64 + lane]);
+            }
+    frag_t *wl3 = (frag_t *) (wl + wave * kResTileBytes);  // unit tile wave + 12, private to this wave
+    frag_t *wl4 = (frag_t *) (wl + 4 * kResTileBytes);     // unit tile 16, wave 0 only
+    for (int gt = 0; gt < 3; ++gt)
+        for (int blk = 0; blk < NBH; ++blk) {
+            wl3[(blk * 3 + gt) * 64 + lane] = whh[((size_t) ((wave + 12) * 3 + gt) * NBH + blk) * 64 + lane];
+            if (wave == 0) wl4[(blk * 3 + gt) * 64 + lane] = whh[((size_t) (16 * 3 + gt) * NBH + blk) * 64 + lane];
+        }
+    for (int i = tid; i < kGateTiles * 16; i += 256) lbias[i] = g.bhh[i];
+
+    f32x4 hreg[kGruTilesPerWave];
+#pragma unroll
+    for (int q = 0; q < kGruTilesPerWave; ++q) {
+        const int u = wave + 4 * q;
+        hreg[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (u < kUnitTiles) hreg[q] = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u) * 64 + lane];
+    }
+    for (int i = tid; i < 2 * NBH * 64; i += 256) ((uint4 *) smem)[i] = uint4{0, 0, 0, 0};
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kGruTilesPerWave; ++q) {
+        const int u = wave + 4 * q;
+        if (u < kUnitTiles) {
+            const int k = u * 16 + colq;
+            uint16_t *dst = (uint16_t *) hbuf0 + (k / P::KB) * 64 * P::EPL;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[P::off(rowq + i, k % P::KB)] = P::cvt(hreg[q][i]);
+        }
+    }
+    // pre-activations of step 0
+    P::gi_t gi[kGruTilesPerWave][3];
+    {
+        const P::gi_t *gp = (const P::gi_t *) g.gi + (size_t) mt * kGateTiles * 64;
+#pragma unroll
+        for (int q = 0; q < kGruTilesPerWave; ++q)
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt) {
+                const int u = wave + 4 * q;
+                if (u < kUnitTiles) gi[q][gt] = gp[(u * 3 + gt) * 64 + lane];
+            }
+    }
+    __syncthreads();
+
+    for (int t = 0; t < g.T; ++t) {
+        KNS_STAMP(0);
+        const char *hc = (t & 1) ? hbuf1 : hbuf0;
+        char *hn = (t & 1) ? hbuf0 : hbuf1;
+        frag_t a[NBH];
+#pragma unroll
+        for (int blk = 0; blk < NBH; ++blk) a[blk] = ((const frag_t *) hc)[blk * 64 + lane];
+        if (t > 0) {  // LDS holds h_{t-1}: publish it as the next layer's A operand
+            frag_t *hs = (frag_t *) g.hseq + ((size_t) (t - 1) * g.mtiles + mt) * NBH * 64;
+#pragma unroll
+            for (int blk = 0; blk < NBH; ++blk)
+                if ((blk & 3) == wave) hs[blk * 64 + lane] = a[blk];
+        }
+        KNS_STAMP(1);
+        const P::gi_t *gnext =
+            (const P::gi_t *) g.gi + ((size_t) (t + 1 < g.T ? t + 1 : t) * g.mtiles + mt) * kGateTiles * 64;
+#pragma unroll
+        for (int q = 0; q < kGruTilesPerWave; ++q) {
+            const int u = wave + 4 * q;
+            if (q < 4 || wave == 0) {
+                f32x4 acc[3];
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (q < 3) {
+#pragma unroll
+                    for (int blk = 0; blk < NBH; ++blk)
+#pragma unroll
+                        for (int gt = 0; gt < 3; ++gt)
+                            acc[gt] = P::mma(a[blk], q == 0 ? wv[gt][blk] : wa[q == 2 ? 1 : 0][gt][blk], acc[gt]);
+                } else {
+                    mma_lds_tile<NBH, 6>(acc, a, q == 3 ? wl3 : wl4, lane);
+                }
+                f32x4 ir = P::from_gi(gi[q][0]), iz = P::from_gi(gi[q][1]), in = P::from_gi(gi[q][2]);
+                // this tile's pre-activations of the next step: in flight while the other tiles compute
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt) gi[q][gt] = gnext[(u * 3 + gt) * 64 + lane];
+                const float br = lbias[(u * 3 + 0) * 16 + colq], bz = lbias[(u * 3 + 1) * 16 + colq],
+                            bn = lbias[(u * 3 + 2) * 16 + colq];
+                const int k = u * 16 + colq;
+                uint16_t *dst = (uint16_t *) hn + (k / P::KB) * 64 * P::EPL + P::off(rowq, k % P::KB);
+                const f32x2 vbr = {br, br}, vbz = {bz, bz}, vbn = {bn, bn};
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const f32x2 ar = {acc[0][2 * p], acc[0][2 * p + 1]}, az = {acc[1][2 * p], acc[1][2 * p + 1]},
+                                an = {acc[2][2 * p], acc[2][2 * p + 1]};
+                    const f32x2 xr = {ir[2 * p], ir[2 * p + 1]}, xz = {iz[2 * p], iz[2 * p + 1]},
+                                xn = {in[2 * p], in[2 * p + 1]};
+                    const f32x2 r = fast_sigmoid2(xr + (ar + vbr));
+                    const f32x2 z = fast_sigmoid2(xz + (az + vbz));
+                    const f32x2 n = fast_tanh2(r * (an + vbn) + xn);
+                    const f32x2 hp = {hreg[q][2 * p], hreg[q][2 * p + 1]};
+                    const f32x2 h = z * (hp - n) + n;
+                    hreg[q][2 * p] = h[0];
+                    hreg[q][2 * p + 1] = h[1];
+                    const uint32_t bits = __builtin_bit_cast(uint32_t, __builtin_convertvector(h, bf16x2));
+                    dst[(2 * p) * 8] = (uint16_t) bits;  // consecutive rows sit 8 elements apart in an A-packed block
+                    dst[(2 * p + 1) * 8] = (uint16_t) (bits >> 16);
+                }
+                KNS_STAMP(2 + q);
+            }
+        }
+        KNS_STAMP(7);
+        __syncthreads();
+        KNS_STAMP(8);
+    }
+    {
+        const char *hc = (g.T & 1) ? hbuf1 : hbuf0;
+        frag_t *hs = (frag_t *) g.hseq + ((size_t) (g.T - 1) * g.mtiles + mt) * NBH * 64;
+        for (int blk = wave; blk < NBH; blk += 4) hs[blk * 64 + lane] = ((const frag_t *) hc)[blk * 64 + lane];
+    }
+#pragma unroll
+    for (int q = 0; q < kGruTilesPerWave; ++q) {
+        const int u = wave + 4 * q;
+        if (u < kUnitTiles) ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u) * 64 + lane] = hreg[q];
+    }
+}
+
+// ---- low-latency GRU layer: input GEMM + recurrent GEMM + gates of one frame, one wavefront per (unit tile, m-tile).
+// Arithmetic is, operation for operation, what the chunked path does (same MFMA, same k order, gi rounded to its storage
+// type before the gates, same gate formulas per precision), so a stream's samples do not depend on which path ran.
+template <class P>
+__global__ __launch_bounds__(64) void gru_small_kernel(GruSmallArgs g) {
+    typedef typename P::frag_t frag_t;
+    typedef typename P::elem_t elem_t;
+    constexpr int NBH = P::NBH;
+    __shared__ __attribute__((aligned(16))) char hbuf[NBH * 1024];
+    const int lane = threadIdx.x;
+    const int u = blockIdx.x, mt = blockIdx.y;
+    const int colq = lane & 15, rowq = (lane >> 4) * 4;
+    const int nb = g.nb0 + NBH;
+
+    // h_{t-1}: fp32 C-fragments -> operand-typed A-fragments through LDS
+    for (int i = lane; i < NBH * 64; i += 64) ((uint4 *) hbuf)[i] = uint4{0, 0, 0, 0};
+    wave_lds_sync();
+    f32x4 hown = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int v = 0; v < kUnitTiles; ++v) {
+        const f32x4 hv = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + v) * 64 + lane];
+        if (v == u) hown = hv;
+        const int k = v * 16 + colq;
+        elem_t *dst = (elem_t *) hbuf + (k / P::KB) * 64 * P::EPL;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[P::off(rowq + i, k % P::KB)] = P::cvt(hv[i]);
+    }
+    wave_lds_sync();
+
+    const frag_t *wih = (const frag_t *) g.wih, *whh = (const frag_t *) g.whh;
+    f32x4 acci[3], acch[3];
+#pragma unroll
+    for (int gt = 0; gt < 3; ++gt) acci[gt] = acch[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int blk = 0; blk < nb; ++blk) {
+        const frag_t a = blk < g.nb0 ? ((const frag_t *) g.a0)[((size_t) mt * g.nb0 + blk) * 64 + lane]
+                                     : ((const frag_t *) g.a1)[((size_t) mt * NBH + (blk - g.nb0)) * 64 + lane];
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt)
+            acci[gt] = P::mma(a, wih[((size_t) (u * 3 + gt) * nb + blk) * 64 + lane], acci[gt]);
+    }
+#pragma unroll
+    for (int blk = 0; blk < NBH; ++blk) {
+        const frag_t a = ((const frag_t *) hbuf)[blk * 64 + lane];
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt)
+            acch[gt] = P::mma(a, whh[((size_t) (u * 3 + gt) * NBH + blk) * 64 + lane], acch[gt]);
+    }
+    f32x4 gin[3];
+#pragma unroll
+    for (int gt = 0; gt < 3; ++gt) {
+        const float b = g.bih[(u * 3 + gt) * 16 + colq];
+        f32x4 v = acci[gt];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = v[i] + b;
+        gin[gt] = P::from_gi(P::to_gi(v));
+    }
+    const float br = g.bhh[(u * 3 + 0) * 16 + colq], bz = g.bhh[(u * 3 + 1) * 16 + colq],
+                bn = g.bhh[(u * 3 + 2) * 16 + colq];
+    f32x4 hnew;
+    if (P::kPrec == kBf16) {
+        const f32x2 vbr = {br, br}, vbz = {bz, bz}, vbn = {bn, bn};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const f32x2 ar = {acch[0][2 * p], acch[0][2 * p + 1]}, az = {acch[1][2 * p], acch[1][2 * p + 1]},
+                        an = {acch[2][2 * p], acch[2][2 * p + 1]};
+            const f32x2 xr = {gin[0][2 * p], gin[0][2 * p + 1]}, xz = {gin[1][2 * p], gin[1][2 * p + 1]},
+                        xn = {gin[2][2 * p], gin[2][2 * p + 1]};
+            const f32x2 r = fast_sigmoid2(xr + (ar + vbr));
+            const f32x2 z = fast_sigmoid2(xz + (az + vbz));
+            const f32x2 n = fast_tanh2(r * (an + vbn) + xn);
+            const f32x2 hp = {hown[2 * p], hown[2 * p + 1]};
+            const f32x2 h = z * (hp - n) + n;
+            hnew[2 * p] = h[0];
+            hnew[2 * p + 1] = h[1];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float r = kns_sigmoid(gin[0][i] + (acch[0][i] + br));
+            float z = kns_sigmoid(gin[1][i] + (acch[1][i] + bz));
+            float n = kns_tanh(__builtin_fmaf(r, acch[2][i] + bn, gin[2][i]));
+            hnew[i] = __builtin_fmaf(z, hown[i] - n, n);
+        }
+    }
+    ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u) * 64 + lane] = hnew;
+    const int k = u * 16 + colq;
+    elem_t *hs = (elem_t *) g.hseq + ((size_t) mt * NBH + k / P::KB) * 64 * P::EPL;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hs[P::off(rowq + i, k % P::KB)] = P::cvt(hnew[i]);
+}
+
+void launch_gru_small(const GruSmallArgs &a, hipStream_t s) {
+    dim3 grid(kUnitTiles, a.mtiles);
+    if (a.precision == kBf16)
+        hipLaunchKernelGGL(gru_small_kernel<PBF16>, grid, dim3(64), 0, s, a);
+    else
+        hipLaunchKernelGGL(gru_small_kernel<PF32>, grid, dim3(64), 0, s, a);
+}
+
+// ---- 8-wave form of the resident recurrent kernel.  Measured on MI355X: a single wave per SIMD executes its MFMAs and
+// its gate VALU one after the other (a unit tile costs 432 + ~650 cycles), while two waves on one SIMD overlap them.
+// Eight waves of <= 256 registers hold the 459 KiB of W_hh as: wave w owns unit tiles w and w + 8 (wave 0 also tile 16);
+// tile w entirely in VGPRs (27 fragments), the first 14 fragments of tile w + 8 in VGPRs and its last 13 in LDS, tile 16
+// in LDS: 328 KiB of registers + 131 KiB of LDS.  A fragments are re-read from LDS per k-block.
+constexpr int kR8Waves = 8;
+constexpr int kR8RegFrags1 = 14;                      // fragments of the second tile kept in registers
+constexpr int kR8LdsFrags1 = 27 - kR8RegFrags1;       // ... and in LDS
+constexpr int kR8Lds = 2 * PBF16::NBH * 1024 + kR8Waves * kR8LdsFrags1 * 1024 + 27 * 1024 + kResBiasBytes;
+
+// MFMAs of one unit tile whose fragments [first_lds, 27) live in LDS at wl[(i - first_lds)] (i = k_block * 3 + gate) and
+// the rest in wreg[i]; LDS fragments go through a kQ-deep register queue
+template <int kFirstLds, int kQ, int kNReg>
+__device__ __forceinline__ void r8_tile_mma(f32x4 (&acc)[3], const bf16x8 *ha, const bf16x8 (&wreg)[kNReg], const bf16x8 *wl,
+                                            int lane) {
+    constexpr int N = 27;
+    bf16x8 qb[kQ];
+#pragma unroll
+    for (int p = 0; p < kQ; ++p)
+        if (kFirstLds + p < N) qb[p] = wl[p * 64 + lane];
+    bf16x8 a = ha[lane];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (i % 3 == 0 && i > 0) a = ha[(i / 3) * 64 + lane];
+        bf16x8 b;
+        if (i < kFirstLds) {
+            b = wreg[i < kNReg ? i : 0];
+        } else {
+            const int j = i - kFirstLds;
+            b = qb[j % kQ];
+            if (i + kQ < N) qb[j % kQ] = wl[(j + kQ) * 64 + lane];
+        }
+        acc[i % 3] = PBF16::mma(a, b, acc[i % 3]);
+    }
+}
+
+__global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs g) {
+    typedef PBF16 P;
+    typedef P::frag_t frag_t;
+    constexpr int NBH = P::NBH;
+    __shared__ __attribute__((aligned(16))) char smem[kR8Lds + 3 * 1024];
+    char *hbuf0 = smem, *hbuf1 = smem + NBH * 1024;
+    frag_t *wl1 = (frag_t *) (smem + 2 * NBH * 1024);                                   // [8 waves][13][64]
+    frag_t *wl16 = (frag_t *) (smem + 2 * NBH * 1024 + kR8Waves * kR8LdsFrags1 * 1024);  // [27][64], i = blk * 3 + gate
+    float *lbias = (float *) (smem + 2 * NBH * 1024 + kR8Waves * kR8LdsFrags1 * 1024 + 27 * 1024);
+    f32x4 *acc16 = (f32x4 *) (smem + kR8Lds);  // [3 gates][64 lanes]: unit tile 16's accumulators, handed across waves
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = blockIdx.x;
+    const int colq = lane & 15, rowq = (lane >> 4) * 4;
+    const frag_t *whh = (const frag_t *) g.whh;
+    const int u0 = wave, u1 = wave + 8, u2 = 16;
+    // Unit tile 16 (the 17th) would make one wave's serial chain 3 tiles long while the others wait at the barrier.
+    // Its 27 MFMAs are done by waves 5, 6, 7 (one gate each, the full k chain in one accumulator, so the arithmetic is
+    // unchanged), the accumulators cross LDS, and after a barrier waves 0..3 each do the gate math of one of the four
+    // rows a lane owns.
+    const int g16 = wave - 5;         // gate whose tile-16 MFMAs this wave computes (waves 5..7)
+    const bool q16 = wave < 4;        // this wave finishes row (lane >> 4) * 4 + wave of tile 16
+
+    // ---- prologue
+    frag_t w0[27], w1[kR8RegFrags1];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) w0[i] = whh[((size_t) (u0 * 3 + i % 3) * NBH + i / 3) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < kR8RegFrags1; ++i) w1[i] = whh[((size_t) (u1 * 3 + i % 3) * NBH + i / 3) * 64 + lane];
+    frag_t *wl1w = wl1 + wave * kR8LdsFrags1 * 64;
+    for (int i = kR8RegFrags1; i < 27; ++i)
+        wl1w[(i - kR8RegFrags1) * 64 + lane] = whh[((size_t) (u1 * 3 + i % 3) * NBH + i / 3) * 64 + lane];
+    for (int i = wave; i < 27; i += kR8Waves) wl16[i * 64 + lane] = whh[((size_t) (u2 * 3 + i % 3) * NBH + i / 3) * 64 + lane];
+    for (int i = tid; i < kGateTiles * 16; i += 64 * kR8Waves) lbias[i] = g.bhh[i];
+
+    f32x4 hreg[2];
+    hreg[0] = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u0) * 64 + lane];
+    hreg[1] = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u1) * 64 + lane];
+    const int e16 = q16 ? wave : 0;  // element of the f32x4 this wave owns in tile 16
+    float h16 = g.hstate_in[(((size_t) mt * kUnitTiles + u2) * 64 + lane) * 4 + e16];
+    for (int i = tid; i < 2 * NBH * 64; i += 64 * kR8Waves) ((uint4 *) smem)[i] = uint4{0, 0, 0, 0};
+    __syncthreads();
+    auto put_h = [&](char *buf, int u, const f32x4 &h) {
+        const int k = u * 16 + colq;
+        uint16_t *dst = (uint16_t *) buf + (k / P::KB) * 64 * P::EPL + P::off(rowq, k % P::KB);
+        const uint32_t lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{h[0], h[1]}, bf16x2));
+        const uint32_t hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{h[2], h[3]}, bf16x2));
+        dst[0] = (uint16_t) lo;  // consecutive rows sit 8 elements apart in an A-packed block
+        dst[8] = (uint16_t) (lo >> 16);
+        dst[16] = (uint16_t) hi;
+        dst[24] = (uint16_t) (hi >> 16);
+    };
+    auto put_h16 = [&](char *buf, float h) {  // one row of tile 16
+        const int k = u2 * 16 + colq;
+        uint16_t *dst = (uint16_t *) buf + (k / P::KB) * 64 * P::EPL + P::off(rowq + e16, k % P::KB);
+        dst[0] = f2bf(h);
+    };
+    put_h(hbuf0, u0, hreg[0]);
+    put_h(hbuf0, u1, hreg[1]);
+    if (q16) put_h16(hbuf0, h16);
+
+    P::gi_t gi[2][3], gi16[3];
+    {
+        const P::gi_t *gp = (const P::gi_t *) g.gi + (size_t) mt * kGateTiles * 64;
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt) {
+            gi[0][gt] = gp[(u0 * 3 + gt) * 64 + lane];
+            gi[1][gt] = gp[(u1 * 3 + gt) * 64 + lane];
+            gi16[gt] = gp[(u2 * 3 + gt) * 64 + lane];
+        }
+    }
+    __syncthreads();
+
+    for (int t = 0; t < g.T; ++t) {
+        KNS_STAMP(0);
+        const char *hc = (t & 1) ? hbuf1 : hbuf0;
+        char *hn = (t & 1) ? hbuf0 : hbuf1;
+        const frag_t *ha = (const frag_t *) hc;
+        if (t > 0) {  // LDS holds h_{t-1}: publish it as the next layer's A operand
+            frag_t *hs = (frag_t *) g.hseq + ((size_t) (t - 1) * g.mtiles + mt) * NBH * 64;
+            for (int blk = wave; blk < NBH; blk += kR8Waves) hs[blk * 64 + lane] = ha[blk * 64 + lane];
+        }
+        const P::gi_t *gnext =
+            (const P::gi_t *) g.gi + ((size_t) (t + 1 < g.T ? t + 1 : t) * g.mtiles + mt) * kGateTiles * 64;
+
+        auto gates = [&](const int q, const int u, f32x4 (&acc)[3]) {
+            const f32x4 ir = P::from_gi(gi[q][0]), iz = P::from_gi(gi[q][1]), in = P::from_gi(gi[q][2]);
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt) gi[q][gt] = gnext[(u * 3 + gt) * 64 + lane];
+            const float br = lbias[(u * 3 + 0) * 16 + colq], bz = lbias[(u * 3 + 1) * 16 + colq],
+                        bn = lbias[(u * 3 + 2) * 16 + colq];
+            const f32x2 vbr = {br, br}, vbz = {bz, bz}, vbn = {bn, bn};
+            f32x4 hnew;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const f32x2 ar = {acc[0][2 * p], acc[0][2 * p + 1]}, az = {acc[1][2 * p], acc[1][2 * p + 1]},
+                            an = {acc[2][2 * p], acc[2][2 * p + 1]};
+                const f32x2 xr = {ir[2 * p], ir[2 * p + 1]}, xz = {iz[2 * p], iz[2 * p + 1]}, xn = {in[2 * p], in[2 * p + 1]};
+                const f32x2 r = fast_sigmoid2(xr + (ar + vbr));
+                const f32x2 z = fast_sigmoid2(xz + (az + vbz));
+                const f32x2 n = fast_tanh2(r * (an + vbn) + xn);
+                const f32x2 hp = {hreg[q][2 * p], hreg[q][2 * p + 1]};
+                const f32x2 h = z * (hp - n) + n;
+                hnew[2 * p] = h[0];
+                hnew[2 * p + 1] = h[1];
+            }
+            hreg[q] = hnew;
+            put_h(hn, u, hnew);
+        };
+
+        KNS_STAMP(1);
+        f32x4 acc[3];
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        r8_tile_mma<27, 1, 27>(acc, ha, w0, wl16, lane);
+        KNS_STAMP(2);
+        gates(0, u0, acc);
+        KNS_STAMP(3);
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        r8_tile_mma<kR8RegFrags1, 3, kR8RegFrags1>(acc, ha, w1, wl1w, lane);
+        KNS_STAMP(4);
+        gates(1, u1, acc);
+        KNS_STAMP(5);
+        if (g16 >= 0) {  // waves 5, 6, 7: one gate of unit tile 16, k-blocks in order in one accumulator
+            f32x4 a16 = f32x4{0.f, 0.f, 0.f, 0.f};
+            frag_t qb[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) qb[p] = wl16[(p * 3 + g16) * 64 + lane];
+#pragma unroll
+            for (int blk = 0; blk < NBH; ++blk) {
+                const frag_t a = ha[blk * 64 + lane];
+                const frag_t b = qb[blk % 3];
+                if (blk + 3 < NBH) qb[blk % 3] = wl16[((blk + 3) * 3 + g16) * 64 + lane];
+                a16 = P::mma(a, b, a16);
+            }
+            acc16[g16 * 64 + lane] = a16;
+        }
+        KNS_STAMP(6);
+        __syncthreads();
+        if (q16) {  // waves 0..3: row e16 of every lane's four rows of unit tile 16
+            const float ar = ((const float *) acc16)[(0 * 64 + lane) * 4 + e16];
+            const float az = ((const float *) acc16)[(1 * 64 + lane) * 4 + e16];
+            const float an = ((const float *) acc16)[(2 * 64 + lane) * 4 + e16];
+            const float xr = (float) gi16[0][e16], xz = (float) gi16[1][e16], xn = (float) gi16[2][e16];
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt) gi16[gt] = gnext[(u2 * 3 + gt) * 64 + lane];
+            const float br = lbias[(u2 * 3 + 0) * 16 + colq], bz = lbias[(u2 * 3 + 1) * 16 + colq],
+                        bn = lbias[(u2 * 3 + 2) * 16 + colq];
+            // same operations, element by element, as the packed gate math above
+            const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((xr + (ar + br)) * -1.44269504088896341f));
+            const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((xz + (az + bz)) * -1.44269504088896341f));
+            const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((r * (an + bn) + xn) * 2.88539008177792681f));
+            const float n = 1.0f - (rr + rr);
+            h16 = z * (h16 - n) + n;
+            put_h16(hn, h16);
+        }
+        KNS_STAMP(7);
+        __syncthreads();
+        KNS_STAMP(8);
+    }
+    {
+        const char *hc = (g.T & 1) ? hbuf1 : hbuf0;
+        frag_t *hs = (frag_t *) g.hseq + ((size_t) (g.T - 1) * g.mtiles + mt) * NBH * 64;
+        for (int blk = wave; blk < NBH; blk += kR8Waves) hs[blk * 64 + lane] = ((const frag_t *) hc)[blk * 64 + lane];
+    }
+    ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u0) * 64 + lane] = hreg[0];
+    ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u1) * 64 + lane] = hreg[1];
+    if (q16) g.hstate_out[(((size_t) mt * kUnitTiles + u2) * 64 + lane) * 4 + e16] = h16;
+}
+
+void launch_gru(const GruArgs &a, hipStream_t s) {
+    static const bool stream_weights = getenv("KOALA_AMD_GRU_STREAM") != nullptr;  // A/B switch for profiling
+    static const bool four_waves = getenv("KOALA_AMD_GRU_4WAVE") != nullptr;  // A/B switch: one wave per SIMD
+    if (a.precision == kBf16 && !stream_weights && !four_waves)
+        hipLaunchKernelGGL(gru_resident8_kernel, dim3(a.mtiles), dim3(64 * kR8Waves), 0, s, a);
+    else if (a.precision == kBf16 && !stream_weights)
+        hipLaunchKernelGGL(gru_resident_kernel, dim3(a.mtiles), dim3(256), 0, s, a);
+    else if (a.precision == kBf16)
+        hipLaunchKernelGGL((gru_kernel<PBF16, 8>), dim3(a.mtiles), dim3(512), 0, s, a);
+    else
+        hipLaunchKernelGGL((gru_kernel<PF32, 8>), dim3(a.mtiles), dim3(512), 0, s, a);
+}
+
+#ifdef KNS_TIMING
+void read_timing(unsigned long long *out) { (void) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kns_timing), sizeof(unsigned long long) * 64); }
+#endif
+
+
+}  // namespace kns

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 lib = os.path.join(ROOT, 'build', 'libpv_koala_timing.so')
 os.makedirs(os.path.dirname(lib), exist_ok=True)
-src = [os.path.join(ROOT, 'koala_amd', 'csrc', f) for f in ('kns_kernels.hip', 'kns_engine.cpp', 'pv_api.cpp')]
+src = [os.path.join(ROOT, 'koala_amd', 'csrc', f) for f in ('kns_stft.hip', 'kns_gemm.hip', 'kns_gru.hip', 'kns_engine.cpp', 'pv_api.cpp')]
 subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
                        '-ffp-contract=off', '-DKNS_TIMING', '-x', 'hip'] + src + ['-shared', '-o', lib])
 import koala_amd
@@ -23,10 +23,6 @@ l = C.CDLL(lib)
 buf = (C.c_ulonglong * 64)()
 l.pv_koala_debug_timing(buf)
 t = np.array(buf[:9], dtype=np.int64)
-w = np.array(buf[16:25], dtype=np.int64)
-w2 = np.array(buf[32:41], dtype=np.int64)
-pass
-print('ws gemm:', {n: int(d) for n, d in zip(['stage issue + A read', 'tile0', 'tile1', 'tile2', 'tile3', 'tile4', 'stage write', 'barrier'], np.diff(w))})
 print('stamps (s_memtime ticks rel.):', (t - t[0]).tolist())
 names = ['top (hseq store)', 'mfma0', 'gates0', 'mfma1', 'gates1', 'tile16 mfma (w5-7)', 'barrier A + tile16 gates', 'barrier B']
 print({n: int(d) for n, d in zip(names, np.diff(t))})
