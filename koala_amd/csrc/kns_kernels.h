@@ -1,4 +1,4 @@
-// kns_kernels.h -- launch interface of the gfx950 kernels (kns_kernels.hip).  Host code only sees PODs.
+// kns_kernels.h -- launch interface of the gfx950 kernels (kns_stft.hip, kns_gemm.hip, kns_gru.hip).  Host code only sees PODs.
 #pragma once
 
 #include <hip/hip_runtime.h>
