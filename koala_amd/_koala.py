@@ -10,102 +10,12 @@ Differences from the reference binding, on purpose:
 
 import os
 from ctypes import (POINTER, Structure, byref, c_char_p, c_int, c_int16, c_int32, c_short, c_void_p, cdll)
-from enum import Enum
 from typing import Sequence
 
+from ._errors import *  # noqa: F401,F403  (re-exported: the reference keeps the exceptions in this module)
+from ._errors import STATUS_TO_EXCEPTION as _STATUS_TO_EXCEPTION
+from ._errors import KoalaInvalidArgumentError, KoalaIOError, PicovoiceStatuses
 
-class KoalaError(Exception):
-    def __init__(self, message: str = '', message_stack: Sequence[str] = None):
-        super().__init__(message)
-        self._message = message
-        self._message_stack = list() if message_stack is None else message_stack
-
-    def __str__(self):
-        lines = [self._message + (':' if self._message_stack else '')]
-        lines += ['  [%d] %s' % (i, m) for i, m in enumerate(self._message_stack)]
-        return '\n'.join(lines)
-
-    @property
-    def message(self) -> str:
-        return self._message
-
-    @property
-    def message_stack(self) -> Sequence[str]:
-        return self._message_stack
-
-
-class KoalaMemoryError(KoalaError):
-    pass
-
-
-class KoalaIOError(KoalaError):
-    pass
-
-
-class KoalaInvalidArgumentError(KoalaError):
-    pass
-
-
-class KoalaStopIterationError(KoalaError):
-    pass
-
-
-class KoalaKeyError(KoalaError):
-    pass
-
-
-class KoalaInvalidStateError(KoalaError):
-    pass
-
-
-class KoalaRuntimeError(KoalaError):
-    pass
-
-
-class KoalaActivationError(KoalaError):
-    pass
-
-
-class KoalaActivationLimitError(KoalaError):
-    pass
-
-
-class KoalaActivationThrottledError(KoalaError):
-    pass
-
-
-class KoalaActivationRefusedError(KoalaError):
-    pass
-
-
-class PicovoiceStatuses(Enum):
-    SUCCESS = 0
-    OUT_OF_MEMORY = 1
-    IO_ERROR = 2
-    INVALID_ARGUMENT = 3
-    STOP_ITERATION = 4
-    KEY_ERROR = 5
-    INVALID_STATE = 6
-    RUNTIME_ERROR = 7
-    ACTIVATION_ERROR = 8
-    ACTIVATION_LIMIT_REACHED = 9
-    ACTIVATION_THROTTLED = 10
-    ACTIVATION_REFUSED = 11
-
-
-_STATUS_TO_EXCEPTION = {
-    PicovoiceStatuses.OUT_OF_MEMORY: KoalaMemoryError,
-    PicovoiceStatuses.IO_ERROR: KoalaIOError,
-    PicovoiceStatuses.INVALID_ARGUMENT: KoalaInvalidArgumentError,
-    PicovoiceStatuses.STOP_ITERATION: KoalaStopIterationError,
-    PicovoiceStatuses.KEY_ERROR: KoalaKeyError,
-    PicovoiceStatuses.INVALID_STATE: KoalaInvalidStateError,
-    PicovoiceStatuses.RUNTIME_ERROR: KoalaRuntimeError,
-    PicovoiceStatuses.ACTIVATION_ERROR: KoalaActivationError,
-    PicovoiceStatuses.ACTIVATION_LIMIT_REACHED: KoalaActivationLimitError,
-    PicovoiceStatuses.ACTIVATION_THROTTLED: KoalaActivationThrottledError,
-    PicovoiceStatuses.ACTIVATION_REFUSED: KoalaActivationRefusedError,
-}
 
 
 def load_library(library_path: str):
@@ -268,20 +178,7 @@ def list_hardware_devices(library_path: str) -> Sequence[str]:
     return result
 
 
-__all__ = [
-    'Koala',
-    'KoalaActivationError',
-    'KoalaActivationLimitError',
-    'KoalaActivationRefusedError',
-    'KoalaActivationThrottledError',
-    'KoalaError',
-    'KoalaIOError',
-    'KoalaInvalidArgumentError',
-    'KoalaInvalidStateError',
-    'KoalaKeyError',
-    'KoalaMemoryError',
-    'KoalaRuntimeError',
-    'KoalaStopIterationError',
-    'PicovoiceStatuses',
-    'list_hardware_devices',
-]
+from . import _errors  # noqa: E402
+
+__all__ = ['Koala', 'list_hardware_devices', 'load_library', 'fetch_error_stack', 'raise_status'] + [
+    n for n in _errors.__all__ if n != 'STATUS_TO_EXCEPTION']
