@@ -194,3 +194,19 @@ def test_ragged_large_batches_take_the_fallback_kernels(random_model, precision,
     ref = np.concatenate([o.process(base), o.process(base)], axis=1)
     got = np.concatenate([y[:8], y2[:8]], axis=1)
     assert lsb(got, ref).max() <= (6 if precision == 'bf16' else 1)
+
+
+@pytest.mark.parametrize('kind', ['random', 'gate'])
+def test_against_committed_golden_vectors(kind):
+    """The engine against tests/golden/kns_v1_golden.npz (written by tools/make_golden.py from the oracle): no oracle
+    run involved."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, 'kns_v1_golden.npz'))
+    model = model_file(kind)
+    for precision, tol in (('fp32', 1), ('bf16', 6)):
+        kb = koala_amd.create_batch('key', 3, 16, precision, model_path=model)
+        y = np.concatenate([kb.process(np.ascontiguousarray(g['pcm'][:, c * 4096:(c + 1) * 4096])) for c in range(3)], axis=1)
+        kb.delete()
+        d = lsb(y, g['%s_%s' % (kind, precision)])
+        assert d.max() <= tol, (precision, int(d.max()))

@@ -155,3 +155,15 @@ def test_stage_entry_points_agree_with_full_path(random_model, test_pcm):
     ones = np.ones(257, np.float32)
     y = oracle.synthesis(spec, ones, tail)
     assert y.dtype == np.int16 and tail.any()
+
+
+def test_oracle_reproduces_committed_golden_vectors(random_model, gate_model):
+    """tests/golden/kns_v1_golden.npz (tools/make_golden.py): the spec pinned as data."""
+    g = np.load(os.path.join(GOLDEN, 'kns_v1_golden.npz'))
+    for kind, model in (('random', random_model), ('gate', gate_model)):
+        for prec, name in ((oracle.PREC_FP32, 'fp32'), (oracle.PREC_BF16, 'bf16')):
+            got = oracle.Oracle(model, 3, prec).process(g['pcm'])
+            want = g['%s_%s' % (kind, name)]
+            # bit-exact on the host that wrote them; another libm may move the window/twiddle tables by an ulp
+            assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+            assert (got == want).mean() > 0.999
