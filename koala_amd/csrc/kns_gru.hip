@@ -6,7 +6,7 @@ namespace kns {
 // ------------------------------------------------------------------------------------------------ recurrent GRU
 
 // Weights streamed from L2 every step (fp32 parity path; bf16 only as an A/B switch).  W waves per workgroup share the
-// 17 unit tiles round-robin; the B fragments of a tile are fetched two k-blocks (six fragments) ahead of their MFMAs, and with W = 8 two waves per SIMD cover each other's latencies.
+// 17 unit tiles round-robin; the B fragments of a tile are fetched four k-blocks (twelve fragments) ahead of their MFMAs, and with W = 8 two waves per SIMD cover each other's latencies.
 template <class P, int W>
 __global__ __launch_bounds__(64 * W, W / 4) void gru_kernel(GruArgs g) {
     typedef typename P::frag_t frag_t;
@@ -64,26 +64,25 @@ __global__ __launch_bounds__(64 * W, W / 4) void gru_kernel(GruArgs g) {
                 // B fragments two k-blocks ahead of their MFMAs, rotated through registers (a rolled loop: unrolling all 51
                 // fp32 k-block/gate pairs makes hipcc materialise an address pair per load and spill)
                 const frag_t *wu = whh + (size_t) u * 3 * NBH * 64 + lane;
-                frag_t b0[3], b1[3], b2[3];
+                constexpr int kAhead = 4;  // k-blocks in flight per wave: 12 fragments = 12 KiB per wave, 96 KiB per CU
+                frag_t bq[kAhead][3];
 #pragma unroll
-                for (int gt = 0; gt < 3; ++gt) {
-                    b0[gt] = wu[(gt * NBH + 0) * 64];
-                    b1[gt] = wu[(gt * NBH + 1) * 64];
-                    b2[gt] = wu[(gt * NBH + 2) * 64];
-                }
+                for (int p = 0; p < kAhead; ++p)
+#pragma unroll
+                    for (int gt = 0; gt < 3; ++gt) bq[p][gt] = wu[(gt * NBH + (p < NBH ? p : NBH - 1)) * 64];
 #pragma nounroll
                 for (int blk = 0; blk < NBH; ++blk) {
                     const frag_t ab = ha[blk * 64 + lane];
                     frag_t bc[3];
 #pragma unroll
                     for (int gt = 0; gt < 3; ++gt) {
-                        bc[gt] = b0[gt];
-                        b0[gt] = b1[gt];
-                        b1[gt] = b2[gt];
-                    }
-                    const int nb = blk + 3 < NBH ? blk + 3 : NBH - 1;
+                        bc[gt] = bq[0][gt];
 #pragma unroll
-                    for (int gt = 0; gt < 3; ++gt) b2[gt] = wu[(gt * NBH + nb) * 64];
+                        for (int p = 0; p + 1 < kAhead; ++p) bq[p][gt] = bq[p + 1][gt];
+                    }
+                    const int nb = blk + kAhead < NBH ? blk + kAhead : NBH - 1;
+#pragma unroll
+                    for (int gt = 0; gt < 3; ++gt) bq[kAhead - 1][gt] = wu[(gt * NBH + nb) * 64];
 #pragma unroll
                     for (int gt = 0; gt < 3; ++gt) acc[gt] = P::mma(ab, bc[gt], acc[gt]);
                 }
