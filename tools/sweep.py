@@ -36,5 +36,5 @@ for T in [int(t) for t in os.environ.get('SWEEP_T', '1,4,16,32,64').split(',')]:
         kb.process_device(T, x.data_ptr(), y.data_ptr())
     p = kb.profile_read()
     print('T=%d  %.3f ms/call  %.2f Mframes/s | ' % (T, dt * 1e3, B * T / dt / 1e6) +
-          '  '.join('%s %.1f us' % (k, v['ms'] / v['launches'] * 1e3) for k, v in p.items()), flush=True)
+          '  '.join('%s %.1f us' % (k, v['ms'] / max(1, v['launches']) * 1e3) for k, v in p.items()), flush=True)
     kb.delete()
