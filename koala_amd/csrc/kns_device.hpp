@@ -26,8 +26,8 @@
 namespace kns {
 
 #ifdef KNS_TIMING
-static __device__ unsigned long long g_kns_timing[64];
-#define KNS_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && t == 5) g_kns_timing[i] = __builtin_amdgcn_s_memtime(); } while (0)
+static __device__ unsigned long long g_kns_timing[8 * 16];  // [wave][stamp] of workgroup 0 at step 5
+#define KNS_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && t == 5) g_kns_timing[(threadIdx.x >> 6) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define KNS_STAMP(i) do { } while (0)
 #endif

@@ -586,7 +586,7 @@ void launch_gru(const GruArgs &a, hipStream_t s) {
 }
 
 #ifdef KNS_TIMING
-void read_timing(unsigned long long *out) { (void) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kns_timing), sizeof(unsigned long long) * 64); }
+void read_timing(unsigned long long *out) { (void) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kns_timing), sizeof(unsigned long long) * 8 * 16); }
 #endif
 
 

@@ -20,9 +20,11 @@ for _ in range(3):
     kb.process_device(T, x.data_ptr(), y.data_ptr())
 kb.synchronize()
 l = C.CDLL(lib)
-buf = (C.c_ulonglong * 64)()
+buf = (C.c_ulonglong * 128)()
 l.pv_koala_debug_timing(buf)
-t = np.array(buf[:9], dtype=np.int64)
-print('stamps (s_memtime ticks rel.):', (t - t[0]).tolist())
-names = ['top (hseq store)', 'mfma0', 'gates0', 'mfma1', 'gates1', 'tile16 mfma (w5-7)', 'barrier A + tile16 gates', 'barrier B']
-print({n: int(d) for n, d in zip(names, np.diff(t))})
+t = np.array(buf[:128], dtype=np.int64).reshape(8, 16)
+n = int(os.environ.get('TIMING_STAMPS', 9))
+base = t[:, 0].min()
+print('per-wave stamps of workgroup 0, step 5 (s_memtime ticks from the earliest stamp 0); rows = waves')
+for w in range(8):
+    print('wave %d:' % w, ' '.join('%6d' % (v - base) for v in t[w, :n]), ' | deltas:', ' '.join('%5d' % d for d in np.diff(t[w, :n])))
