@@ -28,8 +28,10 @@ namespace kns {
 #ifdef KNS_TIMING
 static __device__ unsigned long long g_kns_timing[8 * 16];  // [wave][stamp] of workgroup 0 at step 5
 #define KNS_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && t == 5) g_kns_timing[(threadIdx.x >> 6) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define KNS_STAMP_AT(i, step) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && t == (step)) g_kns_timing[(threadIdx.x >> 6) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define KNS_STAMP(i) do { } while (0)
+#define KNS_STAMP_AT(i, step) do { } while (0)
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -476,6 +476,8 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
 
     for (int t = 0; t < g.T; ++t) {
         KNS_STAMP(0);
+        KNS_STAMP_AT(9, 8);  // steady-state step length = (stamp 10 - stamp 9) / 16
+        KNS_STAMP_AT(10, 24);
         const char *hc = (t & 1) ? hbuf1 : hbuf0;
         char *hn = (t & 1) ? hbuf0 : hbuf1;
         const frag_t *ha = (const frag_t *) hc;

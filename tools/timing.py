@@ -28,3 +28,10 @@ base = t[:, 0].min()
 print('per-wave stamps of workgroup 0, step 5 (s_memtime ticks from the earliest stamp 0); rows = waves')
 for w in range(8):
     print('wave %d:' % w, ' '.join('%6d' % (v - base) for v in t[w, :n]), ' | deltas:', ' '.join('%5d' % d for d in np.diff(t[w, :n])))
+print('steady state: %.0f ticks per step (steps 8..24, wave 0)' % ((t[0, 10] - t[0, 9]) / 16.0))
+kb.profile_enable(True)
+for _ in range(3):
+    kb.process_device(T, x.data_ptr(), y.data_ptr())
+pr = kb.profile_read()
+us = pr['gru_recurrent']['ms'] / pr['gru_recurrent']['launches'] * 1e3
+print('recurrent kernel %.1f us per launch = %.3f us per step -> %.2f GHz' % (us, us / T, (t[0, 10] - t[0, 9]) / 16.0 / (us / T) / 1e3))
