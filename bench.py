@@ -41,12 +41,16 @@ MAC_HEAD = 257 * H + H * sum(HEADS)                       # front-end + 4 heads
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--prime-seconds', type=float, default=0.5,
+                    help='untimed run of the same step before the warmup steps: the MI355X takes a few hundred ms of load to '
+                         'leave its idle clocks (sclk ~100 MHz), and the workload then runs against the 1400 W board power cap')
     ap.add_argument('--streams', type=int, default=4096, help='streams per GPU')
     ap.add_argument('--frames', type=int, default=32, help='frames per stream per call')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--library', default=None, help='alternative libpv_koala.so (developer A/B runs)')
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL over xGMI) for real runs; gloo only to test the '
                     'multi-rank code path on a single-GPU box together with KOALA_BENCH_SHARE_GPU=1')
     args = ap.parse_args()
@@ -89,7 +93,8 @@ def main():
     dx = torch.from_numpy(x).cuda()
     dy = torch.empty_like(dx)
 
-    kb = koala_amd.create_batch('bench', B, T, args.precision, model_path=model, device='gpu:%d' % local_rank)
+    kb = koala_amd.create_batch('bench', B, T, args.precision, model_path=model, device='gpu:%d' % local_rank,
+                               library_path=args.library)
     kb.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def step():
@@ -101,6 +106,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_prime = time.perf_counter()
+    while time.perf_counter() - t_prime < args.prime_seconds:  # clock ramp, untimed (see --prime-seconds)
+        step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -113,7 +122,7 @@ def main():
     value = frames_total / elapsed_max
 
     # ---- per-kernel pass (same workload, HIP events around every launch on the engine's stream)
-    prof_steps = max(2, min(args.steps, 5))
+    prof_steps = max(2, min(args.steps, 20))
     kb.profile_enable(True)
     for _ in range(prof_steps):
         step()

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     typedef PBF16 P;
     typedef P::frag_t frag_t;
     constexpr int NBH = P::NBH;
-    __shared__ __attribute__((aligned(16))) char smem[kR8Lds + 3 * 1024];
+    __shared__ __attribute__((aligned(16))) char smem[kR8Lds + 3 * 1024 + 16];
     char *hbuf0 = smem, *hbuf1 = smem + NBH * 1024;
     frag_t *wl1 = (frag_t *) (smem + 2 * NBH * 1024);                                   // [8 waves][13][64]
     frag_t *wl16 = (frag_t *) (smem + 2 * NBH * 1024 + kR8Waves * kR8LdsFrags1 * 1024);  // [27][64], i = blk * 3 + gate
@@ -418,11 +418,16 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     const frag_t *whh = (const frag_t *) g.whh;
     const int u0 = wave, u1 = wave + 8, u2 = 16;
     // Unit tile 16 (the 17th) would make one wave's serial chain 3 tiles long while the others wait at the barrier.
-    // Its 27 MFMAs are done by waves 5, 6, 7 (one gate each, the full k chain in one accumulator, so the arithmetic is
-    // unchanged), the accumulators cross LDS, and after a barrier waves 0..3 each do the gate math of one of the four
-    // rows a lane owns.
-    const int g16 = wave - 5;         // gate whose tile-16 MFMAs this wave computes (waves 5..7)
+    // The first wave of each SIMD gets the SIMD's issue slots first and is through its two tiles ~1 000 cycles before its
+    // partner (per-wave stamps, tools/timing.py), so tile 16 is done in that slack: waves 1, 2, 3 run its 27 MFMAs (one
+    // gate each, the full k chain in one accumulator, so the arithmetic is unchanged), the accumulators cross LDS behind a
+    // step-count flag, and waves 0..3 each do the gate math of one of the four rows a lane owns.  One barrier per step.
+    const int g16 = wave - 1;         // gate whose tile-16 MFMAs this wave computes (waves 1..3)
+    const bool c16 = wave >= 1 && wave <= 3;
     const bool q16 = wave < 4;        // this wave finishes row (lane >> 4) * 4 + wave of tile 16
+    // flags accessed with explicit ds instructions: a volatile access or a workgroup fence would make hipcc drain every
+    // outstanding global load of the wave (s_waitcnt vmcnt(0)) first
+    const unsigned flag16 = (unsigned) (uintptr_t) (smem + kR8Lds + 3 * 1024);  // [3 gates]: step count of acc16's content
 
     // ---- prologue
     frag_t w0[27], w1[kR8RegFrags1];
@@ -442,6 +447,7 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     const int e16 = q16 ? wave : 0;  // element of the f32x4 this wave owns in tile 16
     float h16 = g.hstate_in[(((size_t) mt * kUnitTiles + u2) * 64 + lane) * 4 + e16];
     for (int i = tid; i < 2 * NBH * 64; i += 64 * kR8Waves) ((uint4 *) smem)[i] = uint4{0, 0, 0, 0};
+    if (tid < 4) ((int *) (smem + kR8Lds + 3 * 1024))[tid] = 0;
     __syncthreads();
     auto put_h = [&](char *buf, int u, const f32x4 &h) {
         const int k = u * 16 + colq;
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
         KNS_STAMP(4);
         gates(1, u1, acc);
         KNS_STAMP(5);
-        if (g16 >= 0) {  // waves 5, 6, 7: one gate of unit tile 16, k-blocks in order in one accumulator
+        if (c16) {  // waves 1, 2, 3: one gate of unit tile 16, k-blocks in order in one accumulator
             f32x4 a16 = f32x4{0.f, 0.f, 0.f, 0.f};
             frag_t qb[3];
 #pragma unroll
@@ -540,10 +546,16 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
                 a16 = P::mma(a, b, a16);
             }
             acc16[g16 * 64 + lane] = a16;
+            // LDS operations of one wave complete in order: whoever sees the flag sees the accumulators
+            asm volatile("ds_write_b32 %0, %1" ::"v"(flag16 + g16 * 4), "v"(t + 1) : "memory");
         }
         KNS_STAMP(6);
-        __syncthreads();
         if (q16) {  // waves 0..3: row e16 of every lane's four rows of unit tile 16
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            i32x4 f;
+            do {
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(f) : "v"(flag16) : "memory");
+            } while (__builtin_amdgcn_readfirstlane(f[0] + f[1] + f[2]) != 3 * (t + 1));
             const float ar = ((const float *) acc16)[(0 * 64 + lane) * 4 + e16];
             const float az = ((const float *) acc16)[(1 * 64 + lane) * 4 + e16];
             const float an = ((const float *) acc16)[(2 * 64 + lane) * 4 + e16];

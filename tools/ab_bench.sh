@@ -1,0 +1,23 @@
+#!/bin/bash
+# Developer tool: sustained (power-capped steady state) A/B of library variants through bench.py.
+#   tools/ab_bench.sh path/to/kns_gru_variant.hip [more variants]   ("-" = the tree as it is)
+cd "$(dirname "$0")/.."
+mkdir -p build/ab
+i=0
+for v in "$@"; do
+  lib=$PWD/build/ab/libv$i.so
+  gru=koala_amd/csrc/kns_gru.hip
+  [ "$v" != "-" ] && gru=$v
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -Ikoala_amd/csrc -x hip \
+      koala_amd/csrc/kns_stft.hip koala_amd/csrc/kns_gemm.hip $gru koala_amd/csrc/kns_engine.cpp koala_amd/csrc/pv_api.cpp \
+      -shared -o $lib || exit 1
+  i=$((i+1))
+done
+for rep in 1 2; do
+  for j in $(seq 0 $((i-1))); do
+    python bench.py --library $PWD/build/ab/libv$j.so --no-cpu-baseline --steps ${AB_STEPS:-600} 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('variant $j rep $rep: %.2f Mframes/s  %.4f ms/step | ' % (d['value']/1e6, d['ms_per_step']) + '  '.join('%s %.1f' % (k, v['avg_launch_ms']*1e3) for k,v in d['stages'].items()))"
+  done
+done

@@ -1,5 +1,7 @@
 // Micro-benchmark: dependent-accumulator latency of v_mfma_f32_16x16x32_bf16 on gfx950.  One wave per SIMD issues 24 MFMAs
-// per iteration round-robin over C independent accumulators (C = 1, 2, 3, 4, 6): cycles per MFMA = max(16, latency / C).
+// per iteration round-robin over C independent accumulators.  Only the C = 1 line is meaningful (back-to-back dependent
+// MFMAs: 32 cycles): for C > 1 hipcc copies the accumulators in and out of the asm block every iteration and the loop
+// drains the matrix pipe each time -- the issue rate with independent accumulators (16-17.5 cycles) is measured in coexec.hip.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
