@@ -46,6 +46,13 @@ PV_API pv_status_t pv_koala_batch_reset(pv_koala_batch_t *object, const uint8_t 
 PV_API pv_status_t pv_koala_batch_num_streams(const pv_koala_batch_t *object, int32_t *num_streams);
 PV_API pv_status_t pv_koala_batch_delay_sample(const pv_koala_batch_t *object, int32_t *delay_sample);
 
+/* Page-locked host memory for `pcm` / `enhanced`.  Host-pointer calls are pipelined in sub-chunks (copy-in, kernels and
+ * copy-out of consecutive sub-chunks overlap); buffers obtained here -- or any other page-locked memory -- are read and
+ * written by the GPU's copy engines directly, ordinary (pageable) buffers go through the handle's staging slots first.
+ * Not tied to a handle; release with pv_koala_batch_host_free (NULL is accepted). */
+PV_API pv_status_t pv_koala_batch_host_alloc(int64_t num_bytes, void **memory);
+PV_API void pv_koala_batch_host_free(void *memory);
+
 /* Run on a caller-provided HIP stream (a hipStream_t passed as void*; NULL = the handle's own stream). */
 PV_API pv_status_t pv_koala_batch_set_stream(pv_koala_batch_t *object, void *hip_stream);
 /* Blocks until everything enqueued by this handle has finished. */

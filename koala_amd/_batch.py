@@ -5,7 +5,7 @@ sample-for-sample what its own `Koala` instance would produce.
 """
 
 import os
-from ctypes import POINTER, byref, c_char_p, c_double, c_int32, c_int64, c_void_p
+from ctypes import POINTER, byref, c_char_p, c_double, c_int16, c_int32, c_int64, c_void_p
 from typing import Optional
 
 import numpy as np
@@ -42,6 +42,11 @@ class KoalaBatch(object):
             fn.restype = PicovoiceStatuses
         lib.pv_koala_batch_delete.argtypes = [c_void_p]
         lib.pv_koala_batch_delete.restype = None
+        lib.pv_koala_batch_host_alloc.argtypes = [c_int64, POINTER(c_void_p)]
+        lib.pv_koala_batch_host_alloc.restype = PicovoiceStatuses
+        lib.pv_koala_batch_host_free.argtypes = [c_void_p]
+        lib.pv_koala_batch_host_free.restype = None
+        self._pinned = []
         lib.pv_koala_batch_debug_read.argtypes = [c_void_p, c_int32, c_void_p, c_int64]
         lib.pv_koala_batch_debug_read.restype = c_int64
 
@@ -73,6 +78,26 @@ class KoalaBatch(object):
         self._check(self._lib.pv_koala_batch_process_chunk(self._handle, a.shape[1] // self.frame_length,
                                                            a.ctypes.data, out.ctypes.data), 'Processing failed')
         return out
+
+    def alloc_host(self, num_frames: int) -> np.ndarray:
+        """int16 [num_streams, num_frames*256] in page-locked host memory (freed by `delete()`): `process()` on such arrays
+        lets the GPU's copy engines move the audio directly instead of through a staging copy."""
+        n = self.num_streams * num_frames * self.frame_length
+        p = c_void_p()
+        self._check(self._lib.pv_koala_batch_host_alloc(2 * n, byref(p)), 'Host allocation failed')
+        self._pinned.append(p)
+        buf = (c_int16 * n).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.int16).reshape(self.num_streams, num_frames * self.frame_length)
+
+    def process_into(self, pcm: np.ndarray, enhanced: np.ndarray) -> None:
+        """Like `process()`, writing into a caller-provided array (both C-contiguous int16 of the same shape)."""
+        for a in (pcm, enhanced):
+            if (not isinstance(a, np.ndarray) or a.dtype != np.int16 or not a.flags['C_CONTIGUOUS'] or a.ndim != 2 or
+                    a.shape[0] != self.num_streams or a.shape[1] % self.frame_length or a.shape != pcm.shape):
+                raise KoalaInvalidArgumentError(
+                    "expected C-contiguous int16 arrays of shape [%d, T*%d]" % (self.num_streams, self.frame_length))
+        self._check(self._lib.pv_koala_batch_process_chunk(self._handle, pcm.shape[1] // self.frame_length,
+                                                           pcm.ctypes.data, enhanced.ctypes.data), 'Processing failed')
 
     def process_device(self, num_frames: int, pcm_ptr: int, enhanced_ptr: int) -> None:
         """Device pointers (e.g. torch_tensor.data_ptr()) of int16 [num_streams, num_frames*256]; asynchronous."""
@@ -118,6 +143,9 @@ class KoalaBatch(object):
         if self._handle:
             self._lib.pv_koala_batch_delete(self._handle)
             self._handle = None
+        for p in getattr(self, '_pinned', []):  # arrays from alloc_host() must not be used after this
+            self._lib.pv_koala_batch_host_free(p)
+        self._pinned = []
 
     def __del__(self):
         try:

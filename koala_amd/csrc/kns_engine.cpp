@@ -11,6 +11,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <thread>
+
 namespace kns {
 
 // ------------------------------------------------------------------------------------------------ parameter file
@@ -223,6 +225,25 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     }
     stream_ = own_stream_;
     use_graph_ = getenv("KOALA_AMD_NO_GRAPH") == nullptr;
+    // host-pointer calls are cut into sub-chunks of host_chunk_ frames (two staging slots = the Tmax-sized buffers)
+    host_chunk_ = Tmax_ / 2 < 1 ? 1 : (Tmax_ / 2 > 16 ? 16 : Tmax_ / 2);
+    host_pipeline_min_bytes_ = (size_t) 4 << 20;  // below this a call is launch-bound: sub-chunks would only add launches
+    if (const char *e = getenv("KOALA_AMD_HOST_CHUNK")) {  // developer/test switch: force a sub-chunk length; 0 = never split
+        const int v = atoi(e);
+        if (v >= 1 && v <= Tmax_ / 2) host_chunk_ = v, host_pipeline_min_bytes_ = 0;
+        if (v == 0) host_chunk_ = Tmax_;
+    }
+    bool ok_sync = hipStreamCreateWithFlags(&copy_in_, hipStreamNonBlocking) == hipSuccess &&
+                   hipStreamCreateWithFlags(&copy_out_, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2 && ok_sync; ++i)
+        ok_sync = hipEventCreateWithFlags(&ev_in_[i], hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&ev_done_[i], hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&ev_out_[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok_sync) {
+        (void) hipGetLastError();
+        *err = "Failed to create HIP streams/events.";
+        return false;
+    }
 
     // ---- tables
     std::vector<float> win(kNfft), tw(2 * kNfft);
@@ -332,6 +353,13 @@ Engine::~Engine() {
     for (void *p : allocs_) (void) hipFree(p);
     if (h_in_) (void) hipHostFree(h_in_);
     if (h_out_) (void) hipHostFree(h_out_);
+    for (int i = 0; i < 2; ++i) {
+        if (ev_in_[i]) (void) hipEventDestroy(ev_in_[i]);
+        if (ev_done_[i]) (void) hipEventDestroy(ev_done_[i]);
+        if (ev_out_[i]) (void) hipEventDestroy(ev_out_[i]);
+    }
+    if (copy_in_) (void) hipStreamDestroy(copy_in_);
+    if (copy_out_) (void) hipStreamDestroy(copy_out_);
     if (own_stream_) (void) hipStreamDestroy(own_stream_);
 }
 
@@ -564,24 +592,117 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     return true;
 }
 
-static bool is_device_pointer(const void *p) {
+enum PointerKind { kPtrPageable = 0, kPtrPinned = 1, kPtrDevice = 2 };
+
+static PointerKind pointer_kind(const void *p) {
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
         (void) hipGetLastError();
-        return false;
+        return kPtrPageable;
     }
-    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+    if (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged) return kPtrDevice;
+    return attr.type == hipMemoryTypeHost ? kPtrPinned : kPtrPageable;
+}
+
+// rows x width bytes between pitched host buffers; large copies are split over a few threads (one core moves ~10 GB/s,
+// which is a tenth of what the GPU consumes)
+static void host_copy_2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows) {
+    auto span = [=](size_t r0, size_t r1) {
+        if (dpitch == width && spitch == width) {
+            memcpy((char *) dst + r0 * width, (const char *) src + r0 * width, (r1 - r0) * width);
+            return;
+        }
+        for (size_t r = r0; r < r1; ++r) memcpy((char *) dst + r * dpitch, (const char *) src + r * spitch, width);
+    };
+    const size_t bytes = width * rows;
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nthreads = bytes >= ((size_t) 4 << 20) ? bytes >> 21 : 1;  // one thread per 2 MiB ...
+    if (nthreads > 8) nthreads = 8;                                  // ... up to 8
+    if (hw && nthreads > hw) nthreads = hw;
+    if (nthreads > rows) nthreads = rows ? rows : 1;
+    if (nthreads <= 1) {
+        span(0, rows);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (size_t i = 1; i < nthreads; ++i) pool.emplace_back(span, rows * i / nthreads, rows * (i + 1) / nthreads);
+    span(0, rows / nthreads);
+    for (std::thread &t : pool) t.join();
+}
+
+// Host-pointer call in sub-chunks of host_chunk_ frames: H2D of chunk c+1, the kernels of chunk c and D2H of chunk c-1 run
+// on three streams.  Pinned user buffers (hipHostMalloc / hipHostRegister / pv_koala_batch_host_alloc) are read and written
+// by the copy engines directly (strided 2D copies); pageable ones go through the engine's pinned staging slots.
+bool Engine::process_host_pipelined(int T, const int16_t *pcm, int16_t *out, bool pinned, std::string *err) {
+    const int Tc = host_chunk_;
+    const int n = (T + Tc - 1) / Tc;
+    const size_t row_user = (size_t) T * kFrame * 2;  // pitch of the caller's [B][T * 256] matrices
+    const size_t slot = (size_t) B_ * Tc * kFrame;     // int16 elements per staging slot
+    bool ok = true;
+    auto check = [&](hipError_t e) { ok = ok && e == hipSuccess; };
+    auto drain_to_user = [&](int c) {  // chunk c's output: staging slot -> caller (pageable path)
+        const int s = c & 1, tc = (c + 1) * Tc <= T ? Tc : T - c * Tc;
+        check(hipEventSynchronize(ev_out_[s]));
+        host_copy_2d((char *) out + (size_t) c * Tc * kFrame * 2, row_user, h_out_ + s * slot, (size_t) tc * kFrame * 2,
+                     (size_t) tc * kFrame * 2, B_);
+    };
+    for (int c = 0; c < n && ok; ++c) {
+        const int s = c & 1, tc = (c + 1) * Tc <= T ? Tc : T - c * Tc;
+        const size_t width = (size_t) tc * kFrame * 2;
+        const char *src = (const char *) pcm + (size_t) c * Tc * kFrame * 2;
+        // ---- copy-in (slot s was last read by the kernels of chunk c - 2)
+        if (c >= 2) check(hipStreamWaitEvent(copy_in_, ev_done_[s], 0));
+        if (pinned) {
+            check(hipMemcpy2DAsync(d_in_ + s * slot, width, src, row_user, width, B_, hipMemcpyHostToDevice, copy_in_));
+        } else {
+            if (c >= 2) check(hipEventSynchronize(ev_in_[s]));  // the H2D of chunk c - 2 has left the staging slot
+            host_copy_2d(h_in_ + s * slot, width, src, row_user, width, B_);
+            check(hipMemcpyAsync(d_in_ + s * slot, h_in_ + s * slot, width * B_, hipMemcpyHostToDevice, copy_in_));
+        }
+        check(hipEventRecord(ev_in_[s], copy_in_));
+        // ---- kernels (d_out_ slot s was last drained by the D2H of chunk c - 2)
+        check(hipStreamWaitEvent(stream_, ev_in_[s], 0));
+        if (c >= 2) check(hipStreamWaitEvent(stream_, ev_out_[s], 0));
+        if (ok && !run_device(tc, d_in_ + s * slot, d_out_ + s * slot, err)) return false;
+        check(hipEventRecord(ev_done_[s], stream_));
+        // ---- copy-out
+        check(hipStreamWaitEvent(copy_out_, ev_done_[s], 0));
+        if (pinned) {
+            check(hipMemcpy2DAsync((char *) out + (size_t) c * Tc * kFrame * 2, row_user, d_out_ + s * slot, width, width, B_,
+                                   hipMemcpyDeviceToHost, copy_out_));
+        } else {
+            if (c >= 2) drain_to_user(c - 2);  // frees staging slot s
+            check(hipMemcpyAsync(h_out_ + s * slot, d_out_ + s * slot, width * B_, hipMemcpyDeviceToHost, copy_out_));
+        }
+        check(hipEventRecord(ev_out_[s], copy_out_));
+    }
+    if (ok && !pinned) {
+        if (n >= 2) drain_to_user(n - 2);
+        drain_to_user(n - 1);
+    }
+    if (ok && pinned) {
+        check(hipEventSynchronize(ev_out_[(n - 1) & 1]));
+        if (n >= 2) check(hipEventSynchronize(ev_out_[(n - 2) & 1]));
+    }
+    if (ok) check(hipStreamSynchronize(stream_));
+    if (!ok) {
+        *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
+        (void) hipDeviceSynchronize();
+    }
+    return ok;
 }
 
 bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err) {
     (void) hipSetDevice(device_);
     const size_t bytes = (size_t) B_ * T * kFrame * 2;
-    const bool dev_in = is_device_pointer(pcm), dev_out = is_device_pointer(out);
-    if (dev_in != dev_out) {
+    const PointerKind kin = pointer_kind(pcm), kout = pointer_kind(out);
+    if ((kin == kPtrDevice) != (kout == kPtrDevice)) {
         *err = "`pcm` and `enhanced` must both be host or both be device memory.";
         return false;
     }
-    if (dev_in) return run_device(T, pcm, out, err);
+    if (kin == kPtrDevice) return run_device(T, pcm, out, err);
+    if (T > host_chunk_ && bytes >= host_pipeline_min_bytes_)
+        return process_host_pipelined(T, pcm, out, kin == kPtrPinned && kout == kPtrPinned, err);
     memcpy(h_in_, pcm, bytes);
     if (T == 1 && use_graph_ && stream_ == own_stream_ && !profiling_) {
         // frame-by-frame streaming: copy-in, the 23 kernels and copy-out replayed as one hipGraph

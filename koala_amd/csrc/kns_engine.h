@@ -88,8 +88,14 @@ private:
     void *d_feat_ = nullptr, *d_e_ = nullptr, *d_y_[kStages - 1] = {nullptr, nullptr, nullptr}, *d_gi_ = nullptr,
          *d_hseq_a_ = nullptr, *d_hseq_b_ = nullptr;
 
-    // staging for host-pointer calls
+    // staging for host-pointer calls: [B][Tmax * 256] each; chunked calls use them as two slots of [B][Tc * 256]
     int16_t *d_in_ = nullptr, *d_out_ = nullptr, *h_in_ = nullptr, *h_out_ = nullptr;
+    // host-pointer calls with more than one sub-chunk: copy-in, compute and copy-out run on three streams
+    bool process_host_pipelined(int T, const int16_t *pcm, int16_t *out, bool pinned, std::string *err);
+    hipStream_t copy_in_ = nullptr, copy_out_ = nullptr;
+    hipEvent_t ev_in_[2] = {nullptr, nullptr}, ev_done_[2] = {nullptr, nullptr}, ev_out_[2] = {nullptr, nullptr};
+    int host_chunk_ = 1;
+    size_t host_pipeline_min_bytes_ = 0;
 
     // hipGraph of one host-pointer frame (copy-in, 23 kernels, copy-out); built on first use
     hipGraphExec_t frame_graph_[2] = {nullptr, nullptr};  // one per parity of the hidden-state ping-pong

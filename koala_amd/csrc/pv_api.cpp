@@ -431,6 +431,34 @@ PV_API pv_status_t pv_koala_batch_set_stream(pv_koala_batch_t *object, void *hip
     return PV_STATUS_SUCCESS;
 }
 
+PV_API pv_status_t pv_koala_batch_host_alloc(int64_t num_bytes, void **memory) {
+    t_stack.clear();
+    if (!memory) {
+        push_error(0x64, "Argument `memory` is NULL.");
+        return PV_STATUS_INVALID_ARGUMENT;
+    }
+    *memory = nullptr;
+    if (num_bytes <= 0) {
+        push_error(0x65, "`num_bytes` should be positive.");
+        return PV_STATUS_INVALID_ARGUMENT;
+    }
+    if (kns::visible_gpu_count() <= 0) {
+        push_error(0x33A, "No GPU is visible: page-locked memory needs the HIP runtime.");
+        return PV_STATUS_RUNTIME_ERROR;
+    }
+    if (hipHostMalloc(memory, (size_t) num_bytes, hipHostMallocPortable) != hipSuccess) {
+        (void) hipGetLastError();
+        *memory = nullptr;
+        push_error(0x33B, "Failed to allocate %lld bytes of page-locked memory.", (long long) num_bytes);
+        return PV_STATUS_OUT_OF_MEMORY;
+    }
+    return PV_STATUS_SUCCESS;
+}
+
+PV_API void pv_koala_batch_host_free(void *memory) {
+    if (memory) (void) hipHostFree(memory);
+}
+
 PV_API pv_status_t pv_koala_batch_synchronize(pv_koala_batch_t *object) {
     t_stack.clear();
     if (!object) {

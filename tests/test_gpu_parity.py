@@ -140,6 +140,40 @@ def test_device_pointers_on_caller_stream(random_model):
     kb.delete()
 
 
+@pytest.mark.parametrize('B,Tmax,T,chunk', [(33, 32, 32, '16'), (33, 32, 21, '16'), (20, 8, 7, '4'), (48, 16, 16, '3'),
+                                            (16, 32, 32, '0'), (5, 2, 2, '1')])
+def test_host_pointer_calls_are_pipelined_without_changing_results(random_model, monkeypatch, B, Tmax, T, chunk):
+    """Host-pointer calls run as overlapping sub-chunks (pageable buffers through staging slots, page-locked ones by direct
+    strided copies): both must equal the device-pointer call bit for bit, across calls and for ragged chunk counts."""
+    torch = pytest.importorskip('torch')
+    monkeypatch.setenv('KOALA_AMD_HOST_CHUNK', chunk)  # small calls are not split unless told to
+    x = synth_streams(B, 2 * T, seed=5)
+    kb = koala_amd.create_batch('key', B, Tmax, 'bf16', model_path=random_model)
+    dx = torch.from_numpy(x).cuda()
+    dy = torch.zeros_like(dx[:, :T * 256].contiguous())
+    ref = []
+    for c in range(2):
+        dxc = dx[:, c * T * 256:(c + 1) * T * 256].contiguous()
+        torch.cuda.synchronize()  # the engine runs on its own stream here
+        kb.process_device(T, dxc.data_ptr(), dy.data_ptr())
+        kb.synchronize()
+        ref.append(dy.cpu().numpy().copy())
+    kb.reset()
+    pageable = [kb.process(np.ascontiguousarray(x[:, c * T * 256:(c + 1) * T * 256])) for c in range(2)]
+    kb.reset()
+    pin_in, pin_out = kb.alloc_host(T), kb.alloc_host(T)
+    pinned = []
+    for c in range(2):
+        pin_in[:] = x[:, c * T * 256:(c + 1) * T * 256]
+        pin_out[:] = -1
+        kb.process_into(pin_in, pin_out)
+        pinned.append(pin_out.copy())
+    kb.delete()
+    for c in range(2):
+        assert np.array_equal(pageable[c], ref[c])
+        assert np.array_equal(pinned[c], ref[c])
+
+
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
 def test_full_batch_unity_mask_is_a_pure_delay(unity_model, precision):
     """BASELINE batch (4096 streams x 32 frames): with mask == 1 the STFT/iSTFT pair must return the input delayed

@@ -1,14 +1,20 @@
 #!/bin/bash
 # Developer tool: sustained (power-capped steady state) A/B of library variants through bench.py.
-#   tools/ab_bench.sh path/to/kns_gru_variant.hip [more variants]   ("-" = the tree as it is)
+#   tools/ab_bench.sh VARIANT [VARIANT ...]   VARIANT = "-" (the tree as it is) | path/to/kns_gru_variant.hip | "-Dflag ..." (extra
+#   hipcc flags for the tree's sources)
 cd "$(dirname "$0")/.."
 mkdir -p build/ab
 i=0
 for v in "$@"; do
   lib=$PWD/build/ab/libv$i.so
   gru=koala_amd/csrc/kns_gru.hip
-  [ "$v" != "-" ] && gru=$v
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -Ikoala_amd/csrc -x hip \
+  flags=""
+  case "$v" in
+    -) ;;
+    -*) flags="$v" ;;
+    *) gru=$v ;;
+  esac
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off $flags -Ikoala_amd/csrc -x hip \
       koala_amd/csrc/kns_stft.hip koala_amd/csrc/kns_gemm.hip $gru koala_amd/csrc/kns_engine.cpp koala_amd/csrc/pv_api.cpp \
       -shared -o $lib || exit 1
   i=$((i+1))
