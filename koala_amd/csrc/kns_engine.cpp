@@ -478,8 +478,10 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     an.T = T;
     an.nbf = nbf_;
     an.precision = prec_;
+    // developer switch (power / clock probing, results are garbage): launch only the kernels of one class
+    static const int only = getenv("KOALA_AMD_ONLY_CLASS") ? atoi(getenv("KOALA_AMD_ONLY_CLASS")) : -1;
     tick(kClsAnalysis);
-    launch_analysis(an, stream_);
+    if (only < 0 || only == kClsAnalysis) launch_analysis(an, stream_);
     tock(kClsAnalysis);
     if (!in_place) hist_cur_ ^= 1;
 
@@ -499,7 +501,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         g.out_kind = kind;
         g.precision = prec_;
         tick(cls);
-        launch_gemm(g, stream_);
+        if (only < 0 || only == cls) launch_gemm(g, stream_);
         tock(cls);
     };
     auto gru = [&](const void *whh, const float *bhh, int layer, void *hseq) {
@@ -514,7 +516,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         g.mtiles = mtb;
         g.precision = prec_;
         tick(kClsGru);
-        launch_gru(g, stream_);
+        if (only < 0 || only == kClsGru) launch_gru(g, stream_);
         tock(kClsGru);
     };
 
@@ -579,7 +581,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     sy.Bpad = Bpad_;
     sy.T = T;
     tick(kClsSynthesis);
-    launch_synthesis(sy, stream_);
+    if (only < 0 || only == kClsSynthesis) launch_synthesis(sy, stream_);
     tock(kClsSynthesis);
     hs_cur_ ^= 1;
     if (!in_place) tail_cur_ ^= 1;
