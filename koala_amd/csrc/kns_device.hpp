@@ -267,6 +267,20 @@ __device__ __forceinline__ void mma_lds_tile(f32x4 (&acc)[3], const bf16x8 (&a)[
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
+// Buffer addressing (descriptor in 4 SGPRs + a 32-bit per-lane offset + a scalar offset): for streams whose per-lane part
+// of the address is a launch constant it takes the 64-bit address arithmetic and the address registers out of the loop.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *) base, 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ bf16x8 buf_load_frag(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store_gi(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f16x4 v) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
+}
+
 __device__ __forceinline__ f32x2 fast_sigmoid2(f32x2 x) {
     f32x2 e = x * f32x2{-1.44269504088896341f, -1.44269504088896341f};
     e = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + f32x2{1.0f, 1.0f};

@@ -1,6 +1,8 @@
 // kns_gemm.hip -- every GEMM over stream-frames: generic, weight-stationary input GEMMs, narrow GEMMs, heads.
 #include "kns_device.hpp"
 
+#include <type_traits>
+
 namespace kns {
 
 // ------------------------------------------------------------------------------------------------ GEMM
@@ -260,6 +262,11 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_kernel(GemmArgs g) {
 constexpr int kWs2Waves = 8;    // two waves per SIMD: one wave's MFMAs run under the other's epilogue VALU
 constexpr int kWs2Tiles = 4;    // n-tiles per wave (the 4th only on some waves): 26 / 8 -> 4,4,3,...
 
+#ifndef WS2_NA
+#define WS2_NA 2
+#endif
+constexpr int kWs2NA = WS2_NA;  // A fragments in flight per wave
+
 template <int NB0, int kWs2Stage>  // kWs2Stage: m-tiles staged per barrier
 __global__ __launch_bounds__(64 * kWs2Waves, 2) void gemm_ws2_kernel(GemmArgs g) {
     typedef PBF16 P;
@@ -296,72 +303,89 @@ __global__ __launch_bounds__(64 * kWs2Waves, 2) void gemm_ws2_kernel(GemmArgs g)
     // The launch guarantees mtiles % (kWs2Stage * gridDim.x / 2) == 0, so every staged m-tile exists.
     constexpr int kStageBlocks = kWs2Stage * NB;
     constexpr int kFetch = (kStageBlocks + kWs2Waves - 1) / kWs2Waves;
-    const frag_t *src[kFetch];
-    size_t step[kFetch];
+    // Buffer-addressed: a stage's A tiles are the kWs2Stage consecutive m-tiles at mt0 of a0 (NB0 blocks each) and a1
+    // (9 blocks each); the per-lane part of every address is lane * 16 (A) or lane * 8 (gi), the rest is scalar.
+    const unsigned lane16 = lane * 16u, lane8 = lane * 8u;
+    unsigned foff[kFetch];  // scalar byte offset of fetch i inside its stage window (of a0 if blk < NB0, else of a1)
 #pragma unroll
     for (int i = 0; i < kFetch; ++i) {
         const int idx = wave + kWs2Waves * i;
         const int m = idx / NB, blk = idx % NB;
-        const int mt = mgroup * kWs2Stage + m;
-        if (blk < NB0) {
-            src[i] = (const frag_t *) g.a0 + ((size_t) mt * NB0 + blk) * 64 + lane;
-            step[i] = (size_t) mstride * NB0 * 64;
-        } else {
-            src[i] = (const frag_t *) g.a1 + ((size_t) mt * P::NBH + (blk - NB0)) * 64 + lane;
-            step[i] = (size_t) mstride * P::NBH * 64;
-        }
+        foff[i] = blk < NB0 ? (unsigned) (m * NB0 + blk) * 1024u : (unsigned) (m * P::NBH + (blk - NB0)) * 1024u;
     }
+    auto fetch = [&](int i, int mt0) {
+        const int blk = (wave + kWs2Waves * i) % NB;
+        const __amdgpu_buffer_rsrc_t r =
+            blk < NB0 ? make_rsrc((const frag_t *) g.a0 + (size_t) mt0 * NB0 * 64, kWs2Stage * (NB0 ? NB0 : 1) * 1024)
+                      : make_rsrc((const frag_t *) g.a1 + (size_t) mt0 * P::NBH * 64, kWs2Stage * P::NBH * 1024);
+        return buf_load_frag(r, lane16, foff[i]);
+    };
 #pragma unroll
     for (int i = 0; i < kFetch; ++i)
-        if (wave + kWs2Waves * i < kStageBlocks) abuf[(wave + kWs2Waves * i) * 64 + lane] = *src[i];
+        if (wave + kWs2Waves * i < kStageBlocks) abuf[(wave + kWs2Waves * i) * 64 + lane] = fetch(i, mgroup * kWs2Stage);
     __syncthreads();
 
-    auto store_tile = [&](P::gi_t *out, int j, f32x4 v) {
+    auto store_tile = [&](__amdgpu_buffer_rsrc_t out, int j, f32x4 v) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[j];
-        out[nt[j] * 64 + lane] = P::to_gi(v);
+        buf_store_gi(out, lane8, nt[j] * 512u, P::to_gi(v));
     };
 
-    int cur = 0;
-    for (int mt0 = mgroup * kWs2Stage; mt0 < g.mtiles; mt0 += mstride) {
-        const bool more = mt0 + mstride < g.mtiles;
-        frag_t stage[kFetch];
+    // The main loop exists twice, for waves with and without a fourth n-tile: with the choice inside the k loop every
+    // k-block carried a scalar branch, and hipcc's s_waitcnt placement across those branches made the MFMA chain wait for
+    // the previous m-tile's stores and the in-flight stage loads (vmcnt(N) with N below what was outstanding).
+    auto main_loop = [&](auto has4_tag) {
+        constexpr bool kHas4 = decltype(has4_tag)::value;
+        int cur = 0;
+        for (int mt0 = mgroup * kWs2Stage; mt0 < g.mtiles; mt0 += mstride) {
+            const bool more = mt0 + mstride < g.mtiles;
+            frag_t stage[kFetch];
 #pragma unroll
-        for (int i = 0; i < kFetch; ++i) {
-            src[i] += step[i];
-            if (more && wave + kWs2Waves * i < kStageBlocks) stage[i] = *src[i];  // in flight during this stage's MFMAs
-        }
+            for (int i = 0; i < kFetch; ++i)
+                if (more && wave + kWs2Waves * i < kStageBlocks) stage[i] = fetch(i, mt0 + mstride);  // in flight during the MFMAs
+            // A fragments roll through kWs2NA registers across the whole stage (kWs2Stage m-tiles x NB k-blocks, contiguous
+            // in LDS): the read of block L + kWs2NA is issued as soon as block L's MFMAs are, and scheduling fences keep it
+            // there (left alone hipcc issues every read right before its use and the wave waits an LDS latency per k-block).
+            const frag_t *ab = abuf + cur * kStageBlocks * 64;
+            frag_t qa[kWs2NA];
 #pragma unroll
-        for (int m = 0; m < kWs2Stage; ++m) {
-            const frag_t *ab = abuf + (cur * kStageBlocks + m * NB) * 64;
-            P::gi_t *out = (P::gi_t *) g.out + (size_t) (mt0 + m) * kGateTiles * 64;
-            // three independent accumulator chains over the always-present n-tiles; A fragments streamed from LDS
-            f32x4 acc[3];
+            for (int p = 0; p < kWs2NA; ++p) qa[p] = ab[p * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            f32x4 acc3 = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int m = 0; m < kWs2Stage; ++m) {
+                const __amdgpu_buffer_rsrc_t out =
+                    make_rsrc((P::gi_t *) g.out + (size_t) (mt0 + m) * kGateTiles * 64, kGateTiles * 512);
+                f32x4 acc[kWs2Tiles];  // independent accumulator chains over the wave's n-tiles
 #pragma unroll
-            for (int blk = 0; blk < NB; ++blk) {
-                const frag_t a = ab[blk * 64 + lane];
+                for (int c = 0; c < kWs2Tiles; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < 3; ++c) acc[c] = P::mma(a, wr[c][blk], acc[c]);
-                if (has4) acc3 = P::mma(a, wr[3][blk], acc3);
+                for (int blk = 0; blk < NB; ++blk) {
+                    const int L = m * NB + blk;
+                    const frag_t a = qa[L % kWs2NA];
+#pragma unroll
+                    for (int c = 0; c < (kHas4 ? 4 : 3); ++c) acc[c] = P::mma(a, wr[c][blk], acc[c]);
+                    if (L + kWs2NA < kStageBlocks) qa[L % kWs2NA] = ab[(L + kWs2NA) * 64 + lane];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (m == kWs2Stage - 1) {
+                    // hand the next stage's A tiles to LDS before this m-tile's stores are issued: vmcnt counts stores too
+                    // on gfx950, so a wait placed after them would also wait for their write acknowledgements
+#pragma unroll
+                    for (int i = 0; i < kFetch; ++i)
+                        if (more && wave + kWs2Waves * i < kStageBlocks)
+                            abuf[((cur ^ 1) * kStageBlocks + wave + kWs2Waves * i) * 64 + lane] = stage[i];
+                }
+#pragma unroll
+                for (int c = 0; c < (kHas4 ? 4 : 3); ++c) store_tile(out, c, acc[c]);
             }
-            if (m == kWs2Stage - 1) {
-                // hand the next stage's A tiles to LDS before this m-tile's stores are issued: vmcnt counts stores too on
-                // gfx950, so a wait placed after them would also wait for their write acknowledgements
-#pragma unroll
-                for (int i = 0; i < kFetch; ++i)
-                    if (more && wave + kWs2Waves * i < kStageBlocks)
-                        abuf[((cur ^ 1) * kStageBlocks + wave + kWs2Waves * i) * 64 + lane] = stage[i];
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) store_tile(out, c, acc[c]);
-            if (has4) store_tile(out, 3, acc3);
+            __syncthreads();
+            cur ^= 1;
         }
-        __syncthreads();
-        cur ^= 1;
-    }
+    };
+    if (has4)
+        main_loop(std::true_type{});
+    else
+        main_loop(std::false_type{});
 }
 
 // ---- weight-stationary form of the narrow GEMMs (front-end 257->271, heads 271->{1,5,40,257}; bf16): 8 waves per

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer tool: sustained (power-capped steady state) A/B of library variants through bench.py.
-#   tools/ab_bench.sh VARIANT [VARIANT ...]   VARIANT = "-" (the tree as it is) | path/to/kns_gru_variant.hip | "-Dflag ..." (extra
+#   tools/ab_bench.sh VARIANT [VARIANT ...]   VARIANT = "-" (the tree as it is) | path/to/kns_gru_variant.hip | path/to/kns_gemm_variant.hip | "-Dflag ..." (extra
 #   hipcc flags for the tree's sources)
 cd "$(dirname "$0")/.."
 mkdir -p build/ab
@@ -8,14 +8,16 @@ i=0
 for v in "$@"; do
   lib=$PWD/build/ab/libv$i.so
   gru=koala_amd/csrc/kns_gru.hip
+  gemm=koala_amd/csrc/kns_gemm.hip
   flags=""
   case "$v" in
     -) ;;
     -*) flags="$v" ;;
+    *gemm*) gemm=$v ;;
     *) gru=$v ;;
   esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off $flags -Ikoala_amd/csrc -x hip \
-      koala_amd/csrc/kns_stft.hip koala_amd/csrc/kns_gemm.hip $gru koala_amd/csrc/kns_engine.cpp koala_amd/csrc/pv_api.cpp \
+      koala_amd/csrc/kns_stft.hip $gemm $gru koala_amd/csrc/kns_engine.cpp koala_amd/csrc/pv_api.cpp \
       -shared -o $lib || exit 1
   i=$((i+1))
 done
