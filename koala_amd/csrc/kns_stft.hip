@@ -37,6 +37,15 @@ __global__ __launch_bounds__(256) void analysis_kernel(AnalysisArgs g) {
         tw[i] = ((const float2 *) g.twiddle)[i];
         win[i] = g.window[i];
     }
+    // the normalisation constants of this lane's bins, once: loaded inside the frame loop they sit behind the spectrum
+    // stores in the vector-memory queue, and waiting for them means waiting for the stores' acknowledgements
+    float nmean[4], nscale[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        nmean[r] = g.mean[lane + 64 * r];
+        nscale[r] = g.scale[lane + 64 * r];
+    }
+    const float nmean_nyq = g.mean[256], nscale_nyq = g.scale[256];
     {
         uint4 *z = (uint4 *) tile;
         for (int i = tid; i < g.nbf * 64; i += 256) z[i] = uint4{0, 0, 0, 0};
@@ -86,10 +95,10 @@ __global__ __launch_bounds__(256) void analysis_kernel(AnalysisArgs g) {
                 pw = xr * xr;
             }
             spec[k] = float2{xr, xi};
-            float ft = (kns_log(pw + 1e-10f) - g.mean[k]) * g.scale[k];
+            float ft = (kns_log(pw + 1e-10f) - nmean[r]) * nscale[r];
             tile[(k / P::KB) * 64 * P::EPL + P::off(row, k % P::KB)] = P::cvt(ft);
             if (k == 0) {
-                float fn = (kns_log(nyq * nyq + 1e-10f) - g.mean[256]) * g.scale[256];
+                float fn = (kns_log(nyq * nyq + 1e-10f) - nmean_nyq) * nscale_nyq;
                 tile[(256 / P::KB) * 64 * P::EPL + P::off(row, 256 % P::KB)] = P::cvt(fn);
             }
         }

@@ -9,15 +9,17 @@ for v in "$@"; do
   lib=$PWD/build/ab/libv$i.so
   gru=koala_amd/csrc/kns_gru.hip
   gemm=koala_amd/csrc/kns_gemm.hip
+  stft=koala_amd/csrc/kns_stft.hip
   flags=""
   case "$v" in
     -) ;;
     -*) flags="$v" ;;
     *gemm*) gemm=$v ;;
+    *stft*) stft=$v ;;
     *) gru=$v ;;
   esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off $flags -Ikoala_amd/csrc -x hip \
-      koala_amd/csrc/kns_stft.hip $gemm $gru koala_amd/csrc/kns_engine.cpp koala_amd/csrc/pv_api.cpp \
+      $stft $gemm $gru koala_amd/csrc/kns_engine.cpp koala_amd/csrc/pv_api.cpp \
       -shared -o $lib || exit 1
   i=$((i+1))
 done
