@@ -276,6 +276,16 @@ __device__ __forceinline__ bf16x8 buf_load_frag(__amdgpu_buffer_rsrc_t r, unsign
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+// 16-byte buffer stores take NO scalar offset here (fold it into the descriptor's base): with one, gfx950 reads the
+// upper data dwords late and hipcc 7.2 lets the next VALU instruction overwrite them (kns_gemm.hip, gemm_wsr_kernel).
+__device__ __forceinline__ void buf_store_frag(__amdgpu_buffer_rsrc_t r, unsigned voff, bf16x8 v) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+}
+__device__ __forceinline__ void buf_store_f32x4(__amdgpu_buffer_rsrc_t r, unsigned voff, f32x4 v) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+}
 __device__ __forceinline__ void buf_store_gi(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f16x4 v) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);

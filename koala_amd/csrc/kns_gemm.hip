@@ -431,78 +431,105 @@ __global__ __launch_bounds__(512, 2) void gemm_wsr_kernel(GemmArgs g) {
     constexpr int kFetch = (kStageBlocks + 7) / 8;
     const int mstride = gridDim.x * kWsrStage;
     const frag_t *a1p = (const frag_t *) g.a1;
+    // Buffer-addressed, bounds-checked by the descriptor: a stage window past the last m-tile reads zeros and stores
+    // nothing, so the loop below carries no conditional vector-memory operation (with them, hipcc's s_waitcnt placement
+    // drained the previous stage's stores -- a write round trip -- at the top of every stage).
+    const unsigned lane16 = lane * 16u;
+    auto stage_rsrc = [&](int mt) {  // window of kWsrStage m-tiles of A starting at m-tile mt
+        const int left = g.mtiles - mt;
+        const int n = left <= 0 ? 0 : (left < kWsrStage ? left : kWsrStage);
+        return make_rsrc(a1p + (size_t) (left > 0 ? mt : 0) * NB * 64, (unsigned) n * NB * 1024u);
+    };
     int mt0 = blockIdx.x * kWsrStage;
-    for (int i = wave; i < kStageBlocks; i += 8)
-        if (mt0 + i / NB < g.mtiles) abuf[i * 64 + lane] = a1p[((size_t) mt0 * NB + i) * 64 + lane];
+    {
+        const __amdgpu_buffer_rsrc_t r = stage_rsrc(mt0);
+#pragma unroll
+        for (int i = 0; i < kFetch; ++i)
+            if (wave + 8 * i < kStageBlocks) abuf[(wave + 8 * i) * 64 + lane] = buf_load_frag(r, lane16, (wave + 8 * i) * 1024u);
+    }
     __syncthreads();
 
-    int cur = 0;
-    for (; mt0 < g.mtiles; mt0 += mstride) {
-        const int mn = mt0 + mstride;
-        frag_t stage[kFetch];
+    // one copy of the main loop per number of live units of the wave (1 .. UW): no per-unit branches in the loop
+    auto main_loop = [&](auto nlive_tag) {
+        constexpr int kLive = decltype(nlive_tag)::value;
+        int cur = 0;
+        for (; mt0 < g.mtiles; mt0 += mstride) {
+            const __amdgpu_buffer_rsrc_t rn = stage_rsrc(mt0 + mstride);
+            frag_t stage[kFetch];
 #pragma unroll
-        for (int i = 0; i < kFetch; ++i) {
-            const int idx = wave + 8 * i;
-            if (idx < kStageBlocks && mn + idx / NB < g.mtiles) stage[i] = a1p[((size_t) mn * NB + idx) * 64 + lane];
-        }
-        if (live[0]) {
+            for (int i = 0; i < kFetch; ++i)
+                if (wave + 8 * i < kStageBlocks) stage[i] = buf_load_frag(rn, lane16, (wave + 8 * i) * 1024u);
 #pragma unroll
             for (int m = 0; m < kWsrStage; ++m) {
                 const int mt = mt0 + m;
-                if (mt < g.mtiles) {
-                    const frag_t *ab = abuf + (cur * kStageBlocks + m * NB) * 64;
-                    frag_t a[NB];
+                const bool valid = mt < g.mtiles;
+                // Output descriptors are per 1 KiB tile (nothing is stored for an m-tile past the end) and the stores carry
+                // no scalar offset: on gfx950 a 16-byte buffer store WITH an SGPR offset reads its upper data dwords late,
+                // and hipcc 7.2 does not keep the next VALU write of those registers away from it (seen as 2.0 = the
+                // sigmoid's "1 + e" in place of a mask value).
+                const unsigned out_bytes = kApack ? (unsigned) units * 1024u : (unsigned) g.ntiles * 1024u;
+                const char *out_mt = (const char *) g.out + (size_t) (valid ? mt : 0) * out_bytes;
+                const unsigned tile_bytes = valid ? 1024u : 0u;
+                const frag_t *ab = abuf + (cur * kStageBlocks + m * NB) * 64;
+                frag_t a[NB];
 #pragma unroll
-                    for (int blk = 0; blk < NB; ++blk) a[blk] = ab[blk * 64 + lane];
+                for (int blk = 0; blk < NB; ++blk) a[blk] = ab[blk * 64 + lane];
 #pragma unroll
-                    for (int q = 0; q < UW; ++q) {
-                        if (live[q]) {
-                            f32x4 acc[NU];
+                for (int q = 0; q < kLive; ++q) {
+                    f32x4 acc[NU];
 #pragma unroll
-                            for (int j = 0; j < NU; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int j = 0; j < NU; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                            for (int blk = 0; blk < NB; ++blk)
+                    for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
-                                for (int j = 0; j < NU; ++j) acc[j] = P::mma(a[blk], wr[q * NU + j][blk], acc[j]);
+                        for (int j = 0; j < NU; ++j) acc[j] = P::mma(a[blk], wr[q * NU + j][blk], acc[j]);
 #pragma unroll
-                            for (int j = 0; j < NU; ++j) {
-                                const int nt = unit[q] * NU + j;
-                                f32x4 v = acc[j];
+                    for (int j = 0; j < NU; ++j) {
+                        const int nt = unit[q] * NU + j;
+                        f32x4 v = acc[j];
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) {
-                                    float x = v[i] + bias[q * NU + j];
-                                    if (kSigmoid) x = kns_sigmoid(x);
-                                    if (kApack && nt * 16 + colq >= g.n_valid) x = 0.0f;
-                                    v[i] = x;
-                                }
-                                if (!kApack) {
-                                    ((f32x4 *) g.out)[((size_t) mt * g.ntiles + nt) * 64 + lane] = v;
-                                } else {
-                                    uint16_t *sc = (uint16_t *) scratch;
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i)
-                                        sc[P::off((lane >> 4) * 4 + i, j * 16 + colq)] = P::cvt(v[i]);
-                                }
-                            }
-                            if (kApack) {
-                                wave_lds_sync();
-                                ((uint4 *) g.out)[((size_t) mt * units + unit[q]) * 64 + lane] = ((const uint4 *) scratch)[lane];
-                                wave_lds_sync();
-                            }
+                        for (int i = 0; i < 4; ++i) {
+                            float x = v[i] + bias[q * NU + j];
+                            if (kSigmoid) x = kns_sigmoid(x);
+                            if (kApack && nt * 16 + colq >= g.n_valid) x = 0.0f;
+                            v[i] = x;
                         }
+                        if (!kApack) {
+                            buf_store_f32x4(make_rsrc(out_mt + (size_t) nt * 1024, tile_bytes), lane16, v);
+                        } else {
+                            uint16_t *sc = (uint16_t *) scratch;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) sc[P::off((lane >> 4) * 4 + i, j * 16 + colq)] = P::cvt(v[i]);
+                        }
+                    }
+                    if (kApack) {
+                        wave_lds_sync();
+                        buf_store_frag(make_rsrc(out_mt + (size_t) unit[q] * 1024, tile_bytes), lane16,
+                                       ((const frag_t *) scratch)[lane]);
+                        wave_lds_sync();
                     }
                 }
             }
-        }
-        frag_t *an = abuf + (cur ^ 1) * kStageBlocks * 64;
+            frag_t *an = abuf + (cur ^ 1) * kStageBlocks * 64;
 #pragma unroll
-        for (int i = 0; i < kFetch; ++i) {
-            const int idx = wave + 8 * i;
-            if (idx < kStageBlocks && mn + idx / NB < g.mtiles) an[idx * 64 + lane] = stage[i];
+            for (int i = 0; i < kFetch; ++i)
+                if (wave + 8 * i < kStageBlocks) an[(wave + 8 * i) * 64 + lane] = stage[i];
+            __syncthreads();
+            cur ^= 1;
         }
-        __syncthreads();
-        cur ^= 1;
-    }
+    };
+    int nlive = 0;
+#pragma unroll
+    for (int q = 0; q < UW; ++q) nlive += live[q] ? 1 : 0;
+    // live units are a prefix (unit q of a wave is wave + 8 q); a wave without any still takes part in the staging
+    if (UW >= 3 && nlive == 3)
+        main_loop(std::integral_constant<int, (UW >= 3 ? 3 : UW)>{});
+    else if (UW >= 2 && nlive == 2)
+        main_loop(std::integral_constant<int, (UW >= 2 ? 2 : UW)>{});
+    else if (nlive == 1)
+        main_loop(std::integral_constant<int, 1>{});
+    else
+        main_loop(std::integral_constant<int, 0>{});
 }
 
 // ---- narrow heads (271 -> 1, 5, 40; bf16): the whole weight image is only 2-4 n-tiles, so every wave keeps ALL of it
