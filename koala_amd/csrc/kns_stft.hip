@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void analysis_kernel(AnalysisArgs g) {
     float *fftbuf = (float *) (smem + 6144);              // 4 waves x kFftBufFloats
     typename P::elem_t *tile = (typename P::elem_t *) (smem + 6144 + 4 * kFftBufFloats * 4);  // nbf KiB, A-packed feature tile
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mt = blockIdx.x, t = blockIdx.y;
     const int mtiles = g.Bpad >> 4;
 
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
     float *fftbuf = (float *) (smem + 6144);
     float *mrow = (float *) (smem + 6144 + 4 * kFftBufFloats * 4);  // [16][kMaskLd] fp32
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mt = blockIdx.x;
     const int mtiles = g.Bpad >> 4;
     // this workgroup produces frames [t0, t1) of its 16 streams; a segment that does not start at 0 first replays
@@ -168,8 +168,14 @@ __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
             if (i < kMaskTiles * 64) mnext[j] = src[i];
         }
     };
-    float2 sk[4], sc[4];
-    auto spec_fetch = [&](int t, int f) {
+    // The spectrum of the next (frame, stream) is requested before the current one is transformed.  Two register sets
+    // alternate between the four streams of a frame, so the set filled last in a frame is the one read first in the next
+    // and the loop carries no register copies (with a single set hipcc rotated it at the back edge, which needs the data
+    // -- and every store before it in the vector-memory queue -- to have arrived).  Every fetch and store in the loop is
+    // unconditional: past the last frame the fetches re-read the last frame, and frames that must not be written get a
+    // zero-length buffer descriptor; conditional vector-memory operations make hipcc's s_waitcnt placement drain the queue.
+    float2 skA[4], scA[4], skB[4], scB[4];
+    auto spec_fetch = [&](float2 (&sk)[4], float2 (&sc)[4], int t, int f) {
         const int b = mt * 16 + wave * 4 + f;
         const float2 *spec = (const float2 *) g.spec + ((size_t) t * g.Bpad + b) * 256;
 #pragma unroll
@@ -180,7 +186,68 @@ __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
         }
     };
     mask_fetch(tb);
-    spec_fetch(tb, 0);
+    spec_fetch(skA, scA, tb, 0);
+    const unsigned lane4 = lane * 4u;
+
+    auto stream = [&](const int t, const int f, const bool emit, float2 (&sk)[4], float2 (&sc)[4], float2 (&nk)[4],
+                      float2 (&nc)[4]) {
+        const int row = wave * 4 + f;
+        const int b = mt * 16 + row;
+        const float *mk_row = mrow + row * kMaskLd;
+        {
+            const int tn = f < 3 ? t : (t + 1 < t1 ? t + 1 : t);
+            spec_fetch(nk, nc, tn, f < 3 ? f + 1 : 0);
+        }
+        cpx v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = lane + 64 * r;
+            float2 xk = sk[r], xc = sc[r];
+            float mk = mk_row[k];
+            float mc = mk_row[256 - k];  // mirrored bin (256 when k == 0)
+            cpx yk, yc;
+            if (k == 0) {
+                yk = {mk * xk.x, 0.0f};
+                yc = {mc * xk.y, 0.0f};
+            } else {
+                yk = {mk * xk.x, mk * xk.y};
+                yc = {mc * xc.x, -(mc * xc.y)};
+            }
+            float2 w = tw[k];
+            cpx e = cadd(yk, yc), d = csub(yk, yc);
+            cpx o = cmul(d, cpx{w.x, -w.y});  // conj(W^k) (yk - yc)
+            // Z' = E + i O (both carry the factor 1/2); fed to the forward FFT with re/im swapped = inverse FFT
+            float zr = 0.5f * (e.x - o.y), zi = 0.5f * (e.y + o.x);
+            v[r] = {zi, zr};
+        }
+        fft256_wave(v, buf, tw, lane);
+        int packed[2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = lane + 64 * r;
+            // swapped output: re <-> im
+            const cpx zz = ((const cpx *) buf)[n];
+            float x0 = zz.y * (1.0f / 256.0f);
+            float x1 = zz.x * (1.0f / 256.0f);
+            float y0 = x0 * win[2 * n], y1 = x1 * win[2 * n + 1];
+            if (r < 2) {
+                float a0 = (tl[f][r].x + y0) * 32768.0f, a1 = (tl[f][r].y + y1) * 32768.0f;
+                a0 = __builtin_fminf(__builtin_fmaxf(__builtin_roundf(a0), -32768.0f), 32767.0f);
+                a1 = __builtin_fminf(__builtin_fmaxf(__builtin_roundf(a1), -32768.0f), 32767.0f);
+                packed[r] = ((int) a0 & 0xffff) | ((int) a1 << 16);
+            } else {
+                tl[f][r - 2] = float2{y0, y1};
+            }
+        }
+        {
+            const bool wr = emit && b < g.B;
+            const __amdgpu_buffer_rsrc_t o =
+                make_rsrc(g.out + (wr ? (size_t) b * row_len + (size_t) t * kFrame : (size_t) 0), wr ? kFrame * 2u : 0u);
+            __builtin_amdgcn_raw_buffer_store_b32(packed[0], o, lane4, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(packed[1], o, lane4 + 256u, 0, 0);
+        }
+        wave_lds_sync();
+    };
 
     for (int t = tb; t < t1; ++t) {
         const bool emit = t >= t0;
@@ -196,71 +263,12 @@ __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
                 for (int r = 0; r < 4; ++r) mrow[(row + r) * kMaskLd + col] = mnext[j][r];
             }
         }
-        if (t + 1 < t1) mask_fetch(t + 1);
+        mask_fetch(t + 1 < t1 ? t + 1 : t);
         __syncthreads();
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const int row = wave * 4 + f;
-            const int b = mt * 16 + row;
-            const float *mk_row = mrow + row * kMaskLd;
-            float2 ck[4], cc[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                ck[r] = sk[r];
-                cc[r] = sc[r];
-            }
-            if (f < 3)
-                spec_fetch(t, f + 1);
-            else if (t + 1 < t1)
-                spec_fetch(t + 1, 0);
-            cpx v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = lane + 64 * r;
-                float2 xk = ck[r], xc = cc[r];
-                float mk = mk_row[k];
-                float mc = mk_row[256 - k];  // mirrored bin (256 when k == 0)
-                cpx yk, yc;
-                if (k == 0) {
-                    yk = {mk * xk.x, 0.0f};
-                    yc = {mc * xk.y, 0.0f};
-                } else {
-                    yk = {mk * xk.x, mk * xk.y};
-                    yc = {mc * xc.x, -(mc * xc.y)};
-                }
-                float2 w = tw[k];
-                cpx e = cadd(yk, yc), d = csub(yk, yc);
-                cpx o = cmul(d, cpx{w.x, -w.y});  // conj(W^k) (yk - yc)
-                // Z' = E + i O (both carry the factor 1/2); fed to the forward FFT with re/im swapped = inverse FFT
-                float zr = 0.5f * (e.x - o.y), zi = 0.5f * (e.y + o.x);
-                v[r] = {zi, zr};
-            }
-            fft256_wave(v, buf, tw, lane);
-            int packed[2];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = lane + 64 * r;
-                // swapped output: re <-> im
-                const cpx zz = ((const cpx *) buf)[n];
-                float x0 = zz.y * (1.0f / 256.0f);
-                float x1 = zz.x * (1.0f / 256.0f);
-                float y0 = x0 * win[2 * n], y1 = x1 * win[2 * n + 1];
-                if (r < 2) {
-                    float a0 = (tl[f][r].x + y0) * 32768.0f, a1 = (tl[f][r].y + y1) * 32768.0f;
-                    a0 = __builtin_fminf(__builtin_fmaxf(__builtin_roundf(a0), -32768.0f), 32767.0f);
-                    a1 = __builtin_fminf(__builtin_fmaxf(__builtin_roundf(a1), -32768.0f), 32767.0f);
-                    packed[r] = ((int) a0 & 0xffff) | ((int) a1 << 16);
-                } else {
-                    tl[f][r - 2] = float2{y0, y1};
-                }
-            }
-            if (emit && b < g.B) {
-                int *o = (int *) (g.out + (size_t) b * row_len + (size_t) t * kFrame);
-                o[lane] = packed[0];
-                o[lane + 64] = packed[1];
-            }
-            wave_lds_sync();
-        }
+        stream(t, 0, emit, skA, scA, skB, scB);
+        stream(t, 1, emit, skB, scB, skA, scA);
+        stream(t, 2, emit, skA, scA, skB, scB);
+        stream(t, 3, emit, skB, scB, skA, scA);
     }
     if (t1 == g.T) {
 #pragma unroll
