@@ -11,6 +11,9 @@ for v in "$@"; do
   gemm=koala_amd/csrc/kns_gemm.hip
   stft=koala_amd/csrc/kns_stft.hip
   flags=""
+  case "$v" in  # "file,flags" = both
+    *,*) flags="${v#*,}"; v="${v%%,*}" ;;
+  esac
   case "$v" in
     -) ;;
     -*) flags="$v" ;;
