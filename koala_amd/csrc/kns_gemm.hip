@@ -632,11 +632,13 @@ void launch_gemm(const GemmArgs &a, hipStream_t s) {
                 hipLaunchKernelGGL(gemm_ws_kernel<1>, dim3(256), dim3(256), 0, s, a);
             else
                 hipLaunchKernelGGL(gemm_ws_kernel<2>, dim3(256), dim3(256), 0, s, a);
-        } else if (a.mtiles % 512 == 0 && a.nb0 < 2) {  // four m-tiles per barrier (NB0 = 2 would spill)
-            if (a.nb0 == 0)
+        } else if (a.mtiles % 512 == 0) {  // four m-tiles per barrier
+            if (a.nb0 == 0)  // (eight per barrier measured the same)
                 hipLaunchKernelGGL((gemm_ws2_kernel<0, 4>), grid, block, 0, s, a);
-            else
+            else if (a.nb0 == 1)
                 hipLaunchKernelGGL((gemm_ws2_kernel<1, 4>), grid, block, 0, s, a);
+            else
+                hipLaunchKernelGGL((gemm_ws2_kernel<2, 4>), grid, block, 0, s, a);
         } else {
             if (a.nb0 == 0)
                 hipLaunchKernelGGL((gemm_ws2_kernel<0, 2>), grid, block, 0, s, a);
