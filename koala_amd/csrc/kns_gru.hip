@@ -92,14 +92,33 @@ __global__ __launch_bounds__(64 * W, W / 4) void gru_kernel(GruArgs g) {
                 f32x4 ir = P::from_gi(gir), iz = P::from_gi(giz), in = P::from_gi(gin);
                 const int k = u * 16 + colq;
                 elem_t *dst = (elem_t *) hbuf[cur ^ 1] + (k / P::KB) * 64 * P::EPL;
+                if (P::kPrec == kBf16) {  // the bf16 configuration's gate arithmetic, identical in every bf16 kernel
+                    const f32x2 vbr = {br, br}, vbz = {bz, bz}, vbn = {bn, bn};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float r = kns_sigmoid(ir[i] + (acc[0][i] + br));
-                    float z = kns_sigmoid(iz[i] + (acc[1][i] + bz));
-                    float n = kns_tanh(__builtin_fmaf(r, acc[2][i] + bn, in[i]));
-                    float h = __builtin_fmaf(z, hreg[q][i] - n, n);
-                    hreg[q][i] = h;
-                    dst[P::off(rowq + i, k % P::KB)] = P::cvt(h);
+                    for (int p = 0; p < 2; ++p) {
+                        const f32x2 ar = {acc[0][2 * p], acc[0][2 * p + 1]}, az = {acc[1][2 * p], acc[1][2 * p + 1]},
+                                    an = {acc[2][2 * p], acc[2][2 * p + 1]};
+                        const f32x2 xr = {ir[2 * p], ir[2 * p + 1]}, xz = {iz[2 * p], iz[2 * p + 1]}, xn = {in[2 * p], in[2 * p + 1]};
+                        const f32x2 r = fast_sigmoid2(xr + (ar + vbr));
+                        const f32x2 z = fast_sigmoid2(xz + (az + vbz));
+                        const f32x2 n = fast_tanh2(r * (an + vbn) + xn);
+                        const f32x2 hp = {hreg[q][2 * p], hreg[q][2 * p + 1]};
+                        const f32x2 h = z * (hp - n) + n;
+                        hreg[q][2 * p] = h[0];
+                        hreg[q][2 * p + 1] = h[1];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dst[P::off(rowq + i, k % P::KB)] = P::cvt(hreg[q][i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float r = kns_sigmoid(ir[i] + (acc[0][i] + br));
+                        float z = kns_sigmoid(iz[i] + (acc[1][i] + bz));
+                        float n = kns_tanh(__builtin_fmaf(r, acc[2][i] + bn, in[i]));
+                        float h = __builtin_fmaf(z, hreg[q][i] - n, n);
+                        hreg[q][i] = h;
+                        dst[P::off(rowq + i, k % P::KB)] = P::cvt(h);
+                    }
                 }
             }
         }

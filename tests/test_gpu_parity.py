@@ -244,3 +244,42 @@ def test_against_committed_golden_vectors(kind):
         kb.delete()
         d = lsb(y, g['%s_%s' % (kind, precision)])
         assert d.max() <= tol, (precision, int(d.max()))
+
+
+_SWITCH_SCRIPT = r'''
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(tests)r)
+import torch  # noqa: F401  (first: see conftest)
+import koala_amd
+from koala_amd.workload import synth_streams
+h = hashlib.sha256()
+for precision, B, T in (('bf16', 4096, 4), ('bf16', 272, 3), ('fp32', 512, 2)):
+    x = np.tile(synth_streams(16, 2 * T, seed=9), ((B + 15) // 16, 1))[:B]
+    kb = koala_amd.create_batch('key', B, T, precision, model_path=%(model)r)
+    for c in range(2):
+        h.update(kb.process(np.ascontiguousarray(x[:, c * T * 256:(c + 1) * T * 256])).tobytes())
+    kb.delete()
+print('DIGEST', h.hexdigest())
+'''
+
+
+def test_alternative_kernels_give_identical_pcm(random_model):
+    """Every A/B switch selects other kernels for the same arithmetic (weight-streaming vs resident recurrent kernels, the
+    one- and two-wave-per-SIMD forms, generic vs weight-stationary GEMMs, ...): the PCM must not change by a bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _SWITCH_SCRIPT % {'root': root, 'tests': os.path.join(root, 'tests'), 'model': random_model}
+    digests = {}
+    for switch in ('', 'KOALA_AMD_GRU_STREAM', 'KOALA_AMD_GRU_4WAVE', 'KOALA_AMD_GEMM_GENERIC', 'KOALA_AMD_GEMM_WS1',
+                   'KOALA_AMD_GEMM_NO_WSR', 'KOALA_AMD_NO_SMALL', 'KOALA_AMD_NO_GRAPH'):
+        env = dict(os.environ)
+        if switch:
+            env[switch] = '1'
+        out = subprocess.run([sys.executable, '-c', script], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, (switch, out.stderr[-2000:])
+        digests[switch] = [ln for ln in out.stdout.splitlines() if ln.startswith('DIGEST')][-1]
+    assert len(set(digests.values())) == 1, digests
