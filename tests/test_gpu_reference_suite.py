@@ -156,3 +156,42 @@ def test_file_demo_cli_single_and_batch(gate_model, tmp_path):
     a, b = samples(single), samples(outdir / 'test.wav')
     assert len(a) == len(b) == 93680 and np.array_equal(a, b)
     assert frame_rms(samples(outdir / 'noise.wav')) < 0.01
+
+
+def test_stream_demo_matches_the_frame_loop(gate_model, tmp_path):
+    """koala_amd.demo.koala_demo_stream (the reference's microphone demo, demo/python/koala_demo_mic.py:75-121, with a
+    raw-PCM byte stream standing in for the recorder): frames arriving on stdin and a replayed WAV must both give exactly
+    what `Koala.process` gives frame by frame, and the reference copy must be the input."""
+    import subprocess
+    import sys
+    import wave
+    from conftest import GOLDEN, ROOT
+    env = dict(__import__('os').environ, PYTHONPATH=ROOT)
+    with wave.open(GOLDEN + '/test.wav') as w:
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+    pcm = pcm[:50 * 256 + 100]  # a trailing partial frame
+    out1, ref1, out2 = tmp_path / 'o1.wav', tmp_path / 'r1.wav', tmp_path / 'o2.wav'
+    r = subprocess.run([sys.executable, '-m', 'koala_amd.demo.koala_demo_stream', '--output_path', str(out1),
+                        '--reference_output_path', str(ref1), '--model_path', gate_model], input=pcm.tobytes(),
+                       capture_output=True, env=env, cwd=ROOT)
+    assert r.returncode == 0 and b'Real time factor' in r.stdout, r.stderr[-2000:]
+    src = tmp_path / 'in.wav'
+    with wave.open(str(src), 'wb') as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes(pcm.tobytes())
+    r = subprocess.run([sys.executable, '-m', 'koala_amd.demo.koala_demo_stream', '--input_path', str(src), '--realtime',
+                        '--output_path', str(out2), '--model_path', gate_model], capture_output=True, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+    def samples(p):
+        with wave.open(str(p)) as w:
+            return np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+    padded = np.zeros(51 * 256, np.int16)
+    padded[:len(pcm)] = pcm
+    k = koala_amd.create('key', model_path=gate_model)
+    want = np.concatenate([np.array(k.process(padded[i * 256:(i + 1) * 256]), np.int16) for i in range(51)])
+    k.delete()
+    assert np.array_equal(samples(out1), want) and np.array_equal(samples(out2), want)
+    assert np.array_equal(samples(ref1), padded)
