@@ -125,12 +125,16 @@ void launch_analysis(const AnalysisArgs &a, hipStream_t s) {
 
 constexpr int kMaskLd = 273;  // row stride (floats) of the row-major mask tile in LDS: odd, so column walks are conflict-free
 
-__global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
+// 8 waves per workgroup, two streams per wave: the grid is only (streams / 16) x segments workgroups (512 at the bench
+// size, two per CU), so with four waves each a SIMD held two waves and every wave paid its FFT's LDS round trips alone.
+constexpr int kSynWaves = 8, kSynStreams = 16 / kSynWaves;
+
+__global__ __launch_bounds__(64 * kSynWaves) void synthesis_kernel(SynthesisArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2 *tw = (float2 *) smem;
     float *win = (float *) (smem + 4096);
     float *fftbuf = (float *) (smem + 6144);
-    float *mrow = (float *) (smem + 6144 + 4 * kFftBufFloats * 4);  // [16][kMaskLd] fp32
+    float *mrow = (float *) (smem + 6144 + kSynWaves * kFftBufFloats * 4);  // [16][kMaskLd] fp32
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mt = blockIdx.x;
@@ -138,18 +142,18 @@ __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
     // this workgroup produces frames [t0, t1) of its 16 streams; a segment that does not start at 0 first replays
     // frame t0 - 1 (no output) to rebuild the overlap-add tail it inherits
     const int t0 = blockIdx.y * g.seg, t1 = min(g.T, t0 + g.seg);
-    for (int i = tid; i < 512; i += 256) {
+    for (int i = tid; i < 512; i += 64 * kSynWaves) {
         tw[i] = ((const float2 *) g.twiddle)[i];
         win[i] = g.window[i];
     }
     float *buf = fftbuf + wave * kFftBufFloats;
     const size_t row_len = (size_t) g.T * kFrame;
 
-    // overlap-add tail of this wave's four streams: lane holds samples 2n, 2n+1 for n = lane, lane + 64
-    float2 tl[4][2];
+    // overlap-add tail of this wave's streams: lane holds samples 2n, 2n+1 for n = lane, lane + 64
+    float2 tl[kSynStreams][2];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-        const int b = mt * 16 + wave * 4 + f;
+    for (int f = 0; f < kSynStreams; ++f) {
+        const int b = mt * 16 + wave * kSynStreams + f;
         const float2 *tp = (const float2 *) (g.tail_in + (size_t) b * kFrame);
         tl[f][0] = tp[lane];
         tl[f][1] = tp[lane + 64];
@@ -158,25 +162,26 @@ __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
     // software pipeline: the mask tile of frame t+1 and the spectrum of the next (frame, stream) are requested from HBM
     // before the current one is transformed; without it every wave sits out one memory latency per frame
     const int tb = (t0 > 0 ? t0 - 1 : 0);
-    constexpr int kMaskVecs = (kMaskTiles * 64 + 255) / 256;  // f32x4 per thread per mask tile
+    constexpr int kSynThreads = 64 * kSynWaves;
+    constexpr int kMaskVecs = (kMaskTiles * 64 + kSynThreads - 1) / kSynThreads;  // f32x4 per thread per mask tile
     f32x4 mnext[kMaskVecs];
     auto mask_fetch = [&](int t) {
         const f32x4 *src = (const f32x4 *) g.mask + ((size_t) t * mtiles + mt) * kMaskTiles * 64;
 #pragma unroll
         for (int j = 0; j < kMaskVecs; ++j) {
-            const int i = tid + 256 * j;
+            const int i = tid + kSynThreads * j;
             if (i < kMaskTiles * 64) mnext[j] = src[i];
         }
     };
     // The spectrum of the next (frame, stream) is requested before the current one is transformed.  Two register sets
-    // alternate between the four streams of a frame, so the set filled last in a frame is the one read first in the next
+    // alternate between the (two) streams of a frame, so the set filled last in a frame is the one read first in the next
     // and the loop carries no register copies (with a single set hipcc rotated it at the back edge, which needs the data
     // -- and every store before it in the vector-memory queue -- to have arrived).  Every fetch and store in the loop is
     // unconditional: past the last frame the fetches re-read the last frame, and frames that must not be written get a
     // zero-length buffer descriptor; conditional vector-memory operations make hipcc's s_waitcnt placement drain the queue.
     float2 skA[4], scA[4], skB[4], scB[4];
     auto spec_fetch = [&](float2 (&sk)[4], float2 (&sc)[4], int t, int f) {
-        const int b = mt * 16 + wave * 4 + f;
+        const int b = mt * 16 + wave * kSynStreams + f;
         const float2 *spec = (const float2 *) g.spec + ((size_t) t * g.Bpad + b) * 256;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -191,12 +196,12 @@ __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
 
     auto stream = [&](const int t, const int f, const bool emit, float2 (&sk)[4], float2 (&sc)[4], float2 (&nk)[4],
                       float2 (&nc)[4]) {
-        const int row = wave * 4 + f;
+        const int row = wave * kSynStreams + f;
         const int b = mt * 16 + row;
         const float *mk_row = mrow + row * kMaskLd;
         {
-            const int tn = f < 3 ? t : (t + 1 < t1 ? t + 1 : t);
-            spec_fetch(nk, nc, tn, f < 3 ? f + 1 : 0);
+            const int tn = f < kSynStreams - 1 ? t : (t + 1 < t1 ? t + 1 : t);
+            spec_fetch(nk, nc, tn, f < kSynStreams - 1 ? f + 1 : 0);
         }
         cpx v[4];
 #pragma unroll
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
         // C-packed fp32 tile [17][64 lanes][4 rows] -> row-major [16][kMaskLd]
 #pragma unroll
         for (int j = 0; j < kMaskVecs; ++j) {
-            const int i = tid + 256 * j;
+            const int i = tid + kSynThreads * j;
             if (i < kMaskTiles * 64) {
                 const int nt = i >> 6, l = i & 63;
                 const int col = nt * 16 + (l & 15), row = (l >> 4) * 4;
@@ -265,15 +270,14 @@ __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
         }
         mask_fetch(t + 1 < t1 ? t + 1 : t);
         __syncthreads();
+        static_assert(kSynStreams == 2, "the two prefetch sets alternate over an even number of streams");
         stream(t, 0, emit, skA, scA, skB, scB);
         stream(t, 1, emit, skB, scB, skA, scA);
-        stream(t, 2, emit, skA, scA, skB, scB);
-        stream(t, 3, emit, skB, scB, skA, scA);
     }
     if (t1 == g.T) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const int b = mt * 16 + wave * 4 + f;
+        for (int f = 0; f < kSynStreams; ++f) {
+            const int b = mt * 16 + wave * kSynStreams + f;
             float2 *tp = (float2 *) (g.tail_out + (size_t) b * kFrame);
             tp[lane] = tl[f][0];
             tp[lane + 64] = tl[f][1];
@@ -282,8 +286,8 @@ __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
 }
 
 void launch_synthesis(const SynthesisArgs &a, hipStream_t s) {
-    size_t lds = 6144 + 4 * kFftBufFloats * 4 + 16 * kMaskLd * 4;
-    hipLaunchKernelGGL(synthesis_kernel, dim3(a.Bpad / 16, (a.T + a.seg - 1) / a.seg), dim3(256), lds, s, a);
+    size_t lds = 6144 + kSynWaves * kFftBufFloats * 4 + 16 * kMaskLd * 4;
+    hipLaunchKernelGGL(synthesis_kernel, dim3(a.Bpad / 16, (a.T + a.seg - 1) / a.seg), dim3(64 * kSynWaves), lds, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------ reset
