@@ -3,7 +3,7 @@
 bench.py -- throughput of the pv_koala_process hot path on MI355X (BASELINE.json metric: 16 kHz frames/sec/GPU at
 batch 4096, configs[2]: bf16 mask GEMMs on MFMA + fp32 FFT).
 
-One "step" = one pv_koala_batch_process_chunk call: 4096 streams x 32 frames (0.512 s of audio per stream) per GPU,
+One "step" = one pv_koala_batch_process_chunk call: 4096 streams x 64 frames (1.024 s of audio per stream) per GPU,
 int16 PCM already resident in HBM, enhanced PCM left in HBM.  N > 1: one process per GPU (torchrun), each rank owns
 its own 4096 streams (weak scaling, no data-path collective); the only collective is the final RCCL all-reduce of
 {frames, max elapsed}.
@@ -47,7 +47,7 @@ def main():
                     help='untimed run of the same step before the warmup steps: the MI355X takes a few hundred ms of load to '
                          'leave its idle clocks (sclk ~100 MHz), and the workload then runs against the 1400 W board power cap')
     ap.add_argument('--streams', type=int, default=4096, help='streams per GPU')
-    ap.add_argument('--frames', type=int, default=32, help='frames per stream per call')
+    ap.add_argument('--frames', type=int, default=64, help='frames per stream per call (64 = 1.02 s of audio)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--library', default=None, help='alternative libpv_koala.so (developer A/B runs)')
@@ -157,8 +157,9 @@ def main():
     try:
         import glob
         pmc_files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json')))
-        if pmc_files and B == 4096 and T == 32 and args.precision == 'bf16':
-            pmc = json.load(open(pmc_files[-1]))
+        pmc = json.load(open(pmc_files[-1])) if pmc_files else {}
+        wl = pmc.pop('_workload', None)
+        if wl == {'streams_per_gpu': B, 'frames_per_call': T, 'dtype': args.precision}:
             for entry in pmc.values():
                 if entry.get('class') == dominant and 'hbm_bytes' in entry:
                     roofline['traffic'] = entry['hbm_bytes']

@@ -35,6 +35,14 @@ def main(pmc_dir, out):
             if frag in k:
                 entry['class'] = cls
         res[k] = entry
+    # the workload the counters belong to (from the bench line of the first pass): bench.py only quotes them for the same one
+    try:
+        line = [l for l in open('%s/pass1.json' % pmc_dir).read().splitlines() if l.startswith('{')][-1]
+        cfg = json.loads(line)['config']
+        res['_workload'] = {'streams_per_gpu': cfg['streams_per_gpu'], 'frames_per_call': cfg['frames_per_call'],
+                            'dtype': json.loads(line)['dtype']}
+    except Exception:
+        pass
     json.dump(res, open(out, 'w'), indent=1, sort_keys=True)
     for k, v in res.items():
         if 'class' in v:
