@@ -28,8 +28,9 @@ def test_no_store_data_hazard_and_no_spills(src, tmp_path):
     # m-tile counts the two-wave form cannot split and behind KOALA_AMD_GEMM_WS1)
     known = ('gemm_ws_kernelILi1E', 'gemm_ws_kernelILi2E')
     spills = {}
-    for name, size in re.findall(r'\.amdhsa_kernel (\S+)[^;]*?; ScratchSize: (\d+)', text, flags=re.S):
+    found = re.findall(r'\.set (\S+)\.has_indirect_call, \d+\n[^\n]*\n; Kernel info:\n(?:;[^\n]*\n)*?; ScratchSize: (\d+)', text)
+    assert found, 'no kernel resource summaries in the assembly'
+    for name, size in found:
         if int(size) and not any(k in name for k in known):
             spills[name] = int(size)
     assert not spills, 'kernels spill registers to scratch: %r' % spills
-    assert '; ScratchSize:' in text
