@@ -343,40 +343,54 @@ __global__ __launch_bounds__(64 * kWs2Waves, 2) void gemm_ws2_kernel(GemmArgs g)
 #pragma unroll
             for (int i = 0; i < kFetch; ++i)
                 if (more && wave + kWs2Waves * i < kStageBlocks) stage[i] = fetch(i, mt0 + mstride);  // in flight during the MFMAs
-            // A fragments roll through kWs2NA registers across the whole stage (kWs2Stage m-tiles x NB k-blocks, contiguous
-            // in LDS): the read of block L + kWs2NA is issued as soon as block L's MFMAs are, and scheduling fences keep it
-            // there (left alone hipcc issues every read right before its use and the wave waits an LDS latency per k-block).
+            // MP = 2 m-tiles at a time against the same register-resident weights (one where the 11-block layers leave
+            // no registers for it): 6 or 8 independent accumulator chains per wave instead of 3 or 4, twice as many MFMAs
+            // between two LDS waits.  A fragments roll through kWs2NA registers per m-tile: the read of block b + kWs2NA
+            // is issued as soon as block b's MFMAs are, and scheduling fences keep it there (left alone hipcc issues every
+            // read right before its use and the wave waits an LDS latency per k-block).
+            constexpr int MP = NB0 < 2 ? 2 : 1;
+            static_assert(kWs2Stage % MP == 0, "m-tiles are processed MP at a time");
             const frag_t *ab = abuf + cur * kStageBlocks * 64;
-            frag_t qa[kWs2NA];
 #pragma unroll
-            for (int p = 0; p < kWs2NA; ++p) qa[p] = ab[p * 64 + lane];
-            __builtin_amdgcn_sched_barrier(0);
+            for (int m = 0; m < kWs2Stage; m += MP) {
+                f32x4 acc[MP][kWs2Tiles];
+                frag_t qa[MP][kWs2NA];
 #pragma unroll
-            for (int m = 0; m < kWs2Stage; ++m) {
-                const __amdgpu_buffer_rsrc_t out =
-                    make_rsrc((P::gi_t *) g.out + (size_t) (mt0 + m) * kGateTiles * 64, kGateTiles * 512);
-                f32x4 acc[kWs2Tiles];  // independent accumulator chains over the wave's n-tiles
+                for (int mm = 0; mm < MP; ++mm) {
 #pragma unroll
-                for (int c = 0; c < kWs2Tiles; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int c = 0; c < kWs2Tiles; ++c) acc[mm][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int p = 0; p < kWs2NA; ++p) qa[mm][p] = ab[((m + mm) * NB + p) * 64 + lane];
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int blk = 0; blk < NB; ++blk) {
-                    const int L = m * NB + blk;
-                    const frag_t a = qa[L % kWs2NA];
 #pragma unroll
-                    for (int c = 0; c < (kHas4 ? 4 : 3); ++c) acc[c] = P::mma(a, wr[c][blk], acc[c]);
-                    if (L + kWs2NA < kStageBlocks) qa[L % kWs2NA] = ab[(L + kWs2NA) * 64 + lane];
+                    for (int c = 0; c < (kHas4 ? 4 : 3); ++c)
+#pragma unroll
+                        for (int mm = 0; mm < MP; ++mm) acc[mm][c] = P::mma(qa[mm][blk % kWs2NA], wr[c][blk], acc[mm][c]);
+                    if (blk + kWs2NA < NB) {
+#pragma unroll
+                        for (int mm = 0; mm < MP; ++mm)
+                            qa[mm][blk % kWs2NA] = ab[((m + mm) * NB + blk + kWs2NA) * 64 + lane];
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (m == kWs2Stage - 1) {
-                    // hand the next stage's A tiles to LDS before this m-tile's stores are issued: vmcnt counts stores too
-                    // on gfx950, so a wait placed after them would also wait for their write acknowledgements
+                if (m == kWs2Stage - MP) {
+                    // hand the next stage's A tiles to LDS before these m-tiles' stores are issued: vmcnt counts stores
+                    // too on gfx950, so a wait placed after them would also wait for their write acknowledgements
 #pragma unroll
                     for (int i = 0; i < kFetch; ++i)
                         if (more && wave + kWs2Waves * i < kStageBlocks)
                             abuf[((cur ^ 1) * kStageBlocks + wave + kWs2Waves * i) * 64 + lane] = stage[i];
                 }
 #pragma unroll
-                for (int c = 0; c < (kHas4 ? 4 : 3); ++c) store_tile(out, c, acc[c]);
+                for (int mm = 0; mm < MP; ++mm) {
+                    const __amdgpu_buffer_rsrc_t out =
+                        make_rsrc((P::gi_t *) g.out + (size_t) (mt0 + m + mm) * kGateTiles * 64, kGateTiles * 512);
+#pragma unroll
+                    for (int c = 0; c < (kHas4 ? 4 : 3); ++c) store_tile(out, c, acc[mm][c]);
+                }
             }
             __syncthreads();
             cur ^= 1;
