@@ -282,6 +282,7 @@ __global__ __launch_bounds__(64 * kWs2Waves, 2) void gemm_ws2_kernel(GemmArgs g)
     const int half = (bid >> 3) & 1;
     const int mgroup = (bid >> 4) * 8 + (bid & 7);      // 0 .. gridDim.x / 2 - 1
     const int mstride = (gridDim.x >> 1) * kWs2Stage;   // m-tiles between consecutive stages of this workgroup
+    const int mlast = mgroup * kWs2Stage + ((g.mtiles - 1 - mgroup * kWs2Stage) / mstride) * mstride;  // last stage first
     const int nt_base = half ? 26 : 0, nt_count = half ? kGateTiles - 26 : 26;
     const frag_t *w = (const frag_t *) g.w;
 
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(64 * kWs2Waves, 2) void gemm_ws2_kernel(GemmArgs g)
     };
 #pragma unroll
     for (int i = 0; i < kFetch; ++i)
-        if (wave + kWs2Waves * i < kStageBlocks) abuf[(wave + kWs2Waves * i) * 64 + lane] = fetch(i, mgroup * kWs2Stage);
+        if (wave + kWs2Waves * i < kStageBlocks) abuf[(wave + kWs2Waves * i) * 64 + lane] = fetch(i, mlast);
     __syncthreads();
 
     auto store_tile = [&](__amdgpu_buffer_rsrc_t out, int j, f32x4 v) {
@@ -334,15 +335,15 @@ __global__ __launch_bounds__(64 * kWs2Waves, 2) void gemm_ws2_kernel(GemmArgs g)
     // The main loop exists twice, for waves with and without a fourth n-tile: with the choice inside the k loop every
     // k-block carried a scalar branch, and hipcc's s_waitcnt placement across those branches made the MFMA chain wait for
     // the previous m-tile's stores and the in-flight stage loads (vmcnt(N) with N below what was outstanding).
-    auto main_loop = [&](auto has4_tag) {
+    auto main_loop = [&](auto has4_tag) {  // (mlast defined above: time-descending traversal)
         constexpr bool kHas4 = decltype(has4_tag)::value;
         int cur = 0;
-        for (int mt0 = mgroup * kWs2Stage; mt0 < g.mtiles; mt0 += mstride) {
-            const bool more = mt0 + mstride < g.mtiles;
+        for (int mt0 = mlast; mt0 >= 0; mt0 -= mstride) {
+            const bool more = mt0 - mstride >= 0;
             frag_t stage[kFetch];
 #pragma unroll
             for (int i = 0; i < kFetch; ++i)
-                if (more && wave + kWs2Waves * i < kStageBlocks) stage[i] = fetch(i, mt0 + mstride);  // in flight during the MFMAs
+                if (more && wave + kWs2Waves * i < kStageBlocks) stage[i] = fetch(i, mt0 - mstride);  // in flight during the MFMAs
             // MP = 2 m-tiles at a time against the same register-resident weights (one where the 11-block layers leave
             // no registers for it): 6 or 8 independent accumulator chains per wave instead of 3 or 4, twice as many MFMAs
             // between two LDS waits.  A fragments roll through kWs2NA registers per m-tile: the read of block b + kWs2NA
@@ -454,9 +455,15 @@ __global__ __launch_bounds__(512, 2) void gemm_wsr_kernel(GemmArgs g) {
         const int n = left <= 0 ? 0 : (left < kWsrStage ? left : kWsrStage);
         return make_rsrc(a1p + (size_t) (left > 0 ? mt : 0) * NB * 64, (unsigned) n * NB * 1024u);
     };
-    int mt0 = blockIdx.x * kWsrStage;
+    // Traversal order follows the memory-side cache (256 MB): the heads read the hidden sequence the recurrent kernel
+    // has just written (last steps freshest) and the mask is read by the synthesis kernel from step 0 on, so they walk
+    // the m-tiles (= time) DOWN; the front-end feeds an input GEMM that walks down, so it walks UP.
+    constexpr bool kDown = OUT != kOutAPlain;
+    const int mfirst = blockIdx.x * kWsrStage;
+    int mt0 = !kDown ? mfirst : (mfirst < g.mtiles ? mfirst + ((g.mtiles - 1 - mfirst) / mstride) * mstride : -1);
+    const int mstep = kDown ? -mstride : mstride;
     {
-        const __amdgpu_buffer_rsrc_t r = stage_rsrc(mt0);
+        const __amdgpu_buffer_rsrc_t r = stage_rsrc(mt0 < 0 ? g.mtiles : mt0);
 #pragma unroll
         for (int i = 0; i < kFetch; ++i)
             if (wave + 8 * i < kStageBlocks) abuf[(wave + 8 * i) * 64 + lane] = buf_load_frag(r, lane16, (wave + 8 * i) * 1024u);
@@ -467,8 +474,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wsr_kernel(GemmArgs g) {
     auto main_loop = [&](auto nlive_tag) {
         constexpr int kLive = decltype(nlive_tag)::value;
         int cur = 0;
-        for (; mt0 < g.mtiles; mt0 += mstride) {
-            const __amdgpu_buffer_rsrc_t rn = stage_rsrc(mt0 + mstride);
+        for (; mt0 >= 0 && mt0 < g.mtiles; mt0 += mstep) {
+            const __amdgpu_buffer_rsrc_t rn = stage_rsrc(mt0 + mstep < 0 ? g.mtiles : mt0 + mstep);
             frag_t stage[kFetch];
 #pragma unroll
             for (int i = 0; i < kFetch; ++i)
@@ -570,20 +577,23 @@ __global__ __launch_bounds__(512, 2) void gemm_head_kernel(GemmArgs g) {
         bias[j] = g.bias[j * 16 + colq];
     }
     const frag_t *a1p = (const frag_t *) g.a1;
+    // m-tiles in DESCENDING order: the A operand is the hidden sequence the recurrent kernel has just written step by step,
+    // so its last steps are the ones still in the 256 MB memory-side cache
     const int stride = gridDim.x * 8;
-    int mt = blockIdx.x * 8 + wave;
+    const int first = blockIdx.x * 8 + wave;
+    int mt = first < g.mtiles ? first + ((g.mtiles - 1 - first) / stride) * stride : -1;
     frag_t an[NB];
-    if (mt < g.mtiles) {
+    if (mt >= 0) {
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk) an[blk] = a1p[((size_t) mt * NB + blk) * 64 + lane];
     }
-    for (; mt < g.mtiles; mt += stride) {
+    for (; mt >= 0; mt -= stride) {
         frag_t a[NB];
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk) a[blk] = an[blk];
-        if (mt + stride < g.mtiles) {
+        if (mt - stride >= 0) {
 #pragma unroll
-            for (int blk = 0; blk < NB; ++blk) an[blk] = a1p[((size_t) (mt + stride) * NB + blk) * 64 + lane];
+            for (int blk = 0; blk < NB; ++blk) an[blk] = a1p[((size_t) (mt - stride) * NB + blk) * 64 + lane];
         }
 #pragma unroll
         for (int pair = 0; pair < NT / 2; ++pair) {
