@@ -419,6 +419,10 @@ __device__ __forceinline__ void r8_tile_mma(f32x4 (&acc)[3], const bf16x8 *ha, c
     }
 }
 
+__device__ __forceinline__ f16x4 buf_load_gi(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+
 __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs g) {
     typedef PBF16 P;
     typedef P::frag_t frag_t;
@@ -499,6 +503,20 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     }
     __syncthreads();
 
+    // Every wave issues the same vector-memory operations every step and none of them sits inside a branch (the hidden
+    // sequence copy is unconditional -- at t = 0 it writes h_{-1} into slot 0, which the same lanes overwrite with h_0 one
+    // step later --, block 8 goes out in eighths, and tile 16's pre-activations are requested by all waves although only
+    // waves 0..3 use them): with conditional loads and stores in the loop hipcc's first vmcnt wait of a step also covered
+    // the pre-activations requested last in the previous step.
+    const unsigned lane8 = lane * 8u;
+    auto publish = [&](const frag_t *src, int slot) {
+        const __amdgpu_buffer_rsrc_t hs = make_rsrc((const frag_t *) g.hseq + ((size_t) slot * g.mtiles + mt) * NBH * 64, NBH * 1024);
+        const unsigned i0 = wave * 64 + lane, i1 = 8 * 64 + wave * 8 + (lane & 7);
+        const frag_t x0 = src[i0];
+        buf_store_frag(hs, i0 * 16u, x0);
+        const frag_t x1 = src[i1];
+        buf_store_frag(hs, lane < 8 ? i1 * 16u : 0x7fffff00u, x1);  // lanes 8..63: past the descriptor's end, dropped
+    };
     for (int t = 0; t < g.T; ++t) {
         KNS_STAMP(0);
         KNS_STAMP_AT(9, 8);  // steady-state step length = (stamp 10 - stamp 9) / 16
@@ -506,17 +524,14 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
         const char *hc = (t & 1) ? hbuf1 : hbuf0;
         char *hn = (t & 1) ? hbuf0 : hbuf1;
         const frag_t *ha = (const frag_t *) hc;
-        if (t > 0) {  // LDS holds h_{t-1}: publish it as the next layer's A operand
-            frag_t *hs = (frag_t *) g.hseq + ((size_t) (t - 1) * g.mtiles + mt) * NBH * 64;
-            for (int blk = wave; blk < NBH; blk += kR8Waves) hs[blk * 64 + lane] = ha[blk * 64 + lane];
-        }
-        const P::gi_t *gnext =
-            (const P::gi_t *) g.gi + ((size_t) (t + 1 < g.T ? t + 1 : t) * g.mtiles + mt) * kGateTiles * 64;
+        publish(ha, t > 0 ? t - 1 : 0);  // LDS holds h_{t-1}
+        const __amdgpu_buffer_rsrc_t gnext = make_rsrc(
+            (const P::gi_t *) g.gi + ((size_t) (t + 1 < g.T ? t + 1 : t) * g.mtiles + mt) * kGateTiles * 64, kGateTiles * 512);
 
         auto gates = [&](const int q, const int u, f32x4 (&acc)[3]) {
             const f32x4 ir = P::from_gi(gi[q][0]), iz = P::from_gi(gi[q][1]), in = P::from_gi(gi[q][2]);
 #pragma unroll
-            for (int gt = 0; gt < 3; ++gt) gi[q][gt] = gnext[(u * 3 + gt) * 64 + lane];
+            for (int gt = 0; gt < 3; ++gt) gi[q][gt] = buf_load_gi(gnext, lane8, (u * 3 + gt) * 512u);
             const float br = lbias[(u * 3 + 0) * 16 + colq], bz = lbias[(u * 3 + 1) * 16 + colq],
                         bn = lbias[(u * 3 + 2) * 16 + colq];
             const f32x2 vbr = {br, br}, vbz = {bz, bz}, vbn = {bn, bn};
@@ -569,37 +584,35 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
             asm volatile("ds_write_b32 %0, %1" ::"v"(flag16 + g16 * 4), "v"(t + 1) : "memory");
         }
         KNS_STAMP(6);
-        if (q16) {  // waves 0..3: row e16 of every lane's four rows of unit tile 16
-            typedef int i32x4 __attribute__((ext_vector_type(4)));
-            i32x4 f;
-            do {
-                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(f) : "v"(flag16) : "memory");
-            } while (__builtin_amdgcn_readfirstlane(f[0] + f[1] + f[2]) != 3 * (t + 1));
-            const float ar = ((const float *) acc16)[(0 * 64 + lane) * 4 + e16];
-            const float az = ((const float *) acc16)[(1 * 64 + lane) * 4 + e16];
-            const float an = ((const float *) acc16)[(2 * 64 + lane) * 4 + e16];
+        {  // (requested by every wave, used by waves 0..3)
             const float xr = (float) gi16[0][e16], xz = (float) gi16[1][e16], xn = (float) gi16[2][e16];
 #pragma unroll
-            for (int gt = 0; gt < 3; ++gt) gi16[gt] = gnext[(u2 * 3 + gt) * 64 + lane];
-            const float br = lbias[(u2 * 3 + 0) * 16 + colq], bz = lbias[(u2 * 3 + 1) * 16 + colq],
-                        bn = lbias[(u2 * 3 + 2) * 16 + colq];
-            // same operations, element by element, as the packed gate math above
-            const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((xr + (ar + br)) * -1.44269504088896341f));
-            const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((xz + (az + bz)) * -1.44269504088896341f));
-            const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((r * (an + bn) + xn) * 2.88539008177792681f));
-            const float n = 1.0f - (rr + rr);
-            h16 = z * (h16 - n) + n;
-            put_h16(hn, h16);
+            for (int gt = 0; gt < 3; ++gt) gi16[gt] = buf_load_gi(gnext, lane8, (u2 * 3 + gt) * 512u);
+            if (q16) {  // waves 0..3: row e16 of every lane's four rows of unit tile 16
+                typedef int i32x4 __attribute__((ext_vector_type(4)));
+                i32x4 f;
+                do {
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(f) : "v"(flag16) : "memory");
+                } while (__builtin_amdgcn_readfirstlane(f[0] + f[1] + f[2]) != 3 * (t + 1));
+                const float ar = ((const float *) acc16)[(0 * 64 + lane) * 4 + e16];
+                const float az = ((const float *) acc16)[(1 * 64 + lane) * 4 + e16];
+                const float an = ((const float *) acc16)[(2 * 64 + lane) * 4 + e16];
+                const float br = lbias[(u2 * 3 + 0) * 16 + colq], bz = lbias[(u2 * 3 + 1) * 16 + colq],
+                            bn = lbias[(u2 * 3 + 2) * 16 + colq];
+                // same operations, element by element, as the packed gate math above
+                const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((xr + (ar + br)) * -1.44269504088896341f));
+                const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((xz + (az + bz)) * -1.44269504088896341f));
+                const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((r * (an + bn) + xn) * 2.88539008177792681f));
+                const float n = 1.0f - (rr + rr);
+                h16 = z * (h16 - n) + n;
+                put_h16(hn, h16);
+            }
         }
         KNS_STAMP(7);
         __syncthreads();
         KNS_STAMP(8);
     }
-    {
-        const char *hc = (g.T & 1) ? hbuf1 : hbuf0;
-        frag_t *hs = (frag_t *) g.hseq + ((size_t) (g.T - 1) * g.mtiles + mt) * NBH * 64;
-        for (int blk = wave; blk < NBH; blk += kR8Waves) hs[blk * 64 + lane] = ((const frag_t *) hc)[blk * 64 + lane];
-    }
+    publish((const frag_t *) ((g.T & 1) ? hbuf1 : hbuf0), g.T - 1);
     ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u0) * 64 + lane] = hreg[0];
     ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u1) * 64 + lane] = hreg[1];
     if (q16) g.hstate_out[(((size_t) mt * kUnitTiles + u2) * 64 + lane) * 4 + e16] = h16;
