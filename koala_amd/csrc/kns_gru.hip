@@ -289,56 +289,77 @@ __global__ __launch_bounds__(256, 1) void gru_resident_kernel(GruArgs g) {
 // Arithmetic is, operation for operation, what the chunked path does (same MFMA, same k order, gi rounded to its storage
 // type before the gates, same gate formulas per precision), so a stream's samples do not depend on which path ran.
 template <class P>
-__global__ __launch_bounds__(64) void gru_small_kernel(GruSmallArgs g) {
+__global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
+    // One workgroup per (unit tile, m-tile), one wave per gate: each wave streams only its gate's weights (a third of the
+    // tile's), four k-blocks of operands requested before the four MFMAs that use them; the three accumulator pairs meet
+    // in LDS and wave 0 does the gate math.  Every accumulator still sums its k-blocks in ascending order, so the result is
+    // bit-identical to the chunked kernels.
     typedef typename P::frag_t frag_t;
     typedef typename P::elem_t elem_t;
     constexpr int NBH = P::NBH;
     __shared__ __attribute__((aligned(16))) char hbuf[NBH * 1024];
-    const int lane = threadIdx.x;
+    __shared__ f32x4 xch[2][3][64];  // [input | recurrent][gate][lane]
+    const int lane = threadIdx.x & 63;
+    const int gt = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // this wave's gate: r, z, n
     const int u = blockIdx.x, mt = blockIdx.y;
     const int colq = lane & 15, rowq = (lane >> 4) * 4;
     const int nb = g.nb0 + NBH;
 
-    // h_{t-1}: fp32 C-fragments -> operand-typed A-fragments through LDS
-    for (int i = lane; i < NBH * 64; i += 64) ((uint4 *) hbuf)[i] = uint4{0, 0, 0, 0};
-    wave_lds_sync();
-    f32x4 hown = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int v = 0; v < kUnitTiles; ++v) {
+    // h_{t-1}: fp32 C-fragments -> operand-typed A-fragments through LDS (the 17 tiles shared out over the three waves)
+    for (int i = threadIdx.x; i < NBH * 64; i += 192) ((uint4 *) hbuf)[i] = uint4{0, 0, 0, 0};
+    __syncthreads();
+    const f32x4 hown = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u) * 64 + lane];
+    for (int v = gt; v < kUnitTiles; v += 3) {
         const f32x4 hv = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + v) * 64 + lane];
-        if (v == u) hown = hv;
         const int k = v * 16 + colq;
         elem_t *dst = (elem_t *) hbuf + (k / P::KB) * 64 * P::EPL;
 #pragma unroll
         for (int i = 0; i < 4; ++i) dst[P::off(rowq + i, k % P::KB)] = P::cvt(hv[i]);
     }
-    wave_lds_sync();
 
-    const frag_t *wih = (const frag_t *) g.wih, *whh = (const frag_t *) g.whh;
-    f32x4 acci[3], acch[3];
+    const frag_t *wih = (const frag_t *) g.wih + (size_t) (u * 3 + gt) * nb * 64 + lane;
+    const frag_t *whh = (const frag_t *) g.whh + (size_t) (u * 3 + gt) * NBH * 64 + lane;
+    const frag_t *a0 = (const frag_t *) g.a0 + (size_t) mt * g.nb0 * 64 + lane;
+    const frag_t *a1 = (const frag_t *) g.a1 + (size_t) mt * NBH * 64 + lane;
+    f32x4 acci = f32x4{0.f, 0.f, 0.f, 0.f}, acch = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int kAhead = 4;
+    for (int b0 = 0; b0 < nb; b0 += kAhead) {
+        frag_t a[kAhead], w[kAhead];
 #pragma unroll
-    for (int gt = 0; gt < 3; ++gt) acci[gt] = acch[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int blk = 0; blk < nb; ++blk) {
-        const frag_t a = blk < g.nb0 ? ((const frag_t *) g.a0)[((size_t) mt * g.nb0 + blk) * 64 + lane]
-                                     : ((const frag_t *) g.a1)[((size_t) mt * NBH + (blk - g.nb0)) * 64 + lane];
+        for (int p = 0; p < kAhead; ++p) {
+            const int blk = b0 + p < nb ? b0 + p : nb - 1;
+            a[p] = blk < g.nb0 ? a0[(size_t) blk * 64] : a1[(size_t) (blk - g.nb0) * 64];
+            w[p] = wih[(size_t) blk * 64];
+        }
 #pragma unroll
-        for (int gt = 0; gt < 3; ++gt)
-            acci[gt] = P::mma(a, wih[((size_t) (u * 3 + gt) * nb + blk) * 64 + lane], acci[gt]);
+        for (int p = 0; p < kAhead; ++p)
+            if (b0 + p < nb) acci = P::mma(a[p], w[p], acci);
     }
+    __syncthreads();  // hbuf complete
 #pragma unroll
-    for (int blk = 0; blk < NBH; ++blk) {
-        const frag_t a = ((const frag_t *) hbuf)[blk * 64 + lane];
+    for (int b0 = 0; b0 < NBH; b0 += kAhead) {
+        frag_t w[kAhead];
 #pragma unroll
-        for (int gt = 0; gt < 3; ++gt)
-            acch[gt] = P::mma(a, whh[((size_t) (u * 3 + gt) * NBH + blk) * 64 + lane], acch[gt]);
+        for (int p = 0; p < kAhead; ++p) w[p] = whh[(size_t) (b0 + p < NBH ? b0 + p : NBH - 1) * 64];
+#pragma unroll
+        for (int p = 0; p < kAhead; ++p)
+            if (b0 + p < NBH) acch = P::mma(((const frag_t *) hbuf)[(b0 + p) * 64 + lane], w[p], acch);
     }
-    f32x4 gin[3];
-#pragma unroll
-    for (int gt = 0; gt < 3; ++gt) {
+    {
         const float b = g.bih[(u * 3 + gt) * 16 + colq];
-        f32x4 v = acci[gt];
+        f32x4 v = acci;
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = v[i] + b;
-        gin[gt] = P::from_gi(P::to_gi(v));
+        xch[0][gt][lane] = P::from_gi(P::to_gi(v));
+        xch[1][gt][lane] = acch;
+    }
+    __syncthreads();
+    if (gt != 0) return;
+    f32x4 gin[3], gh[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        gin[q] = xch[0][q][lane];
+        gh[q] = xch[1][q][lane];
     }
     const float br = g.bhh[(u * 3 + 0) * 16 + colq], bz = g.bhh[(u * 3 + 1) * 16 + colq],
                 bn = g.bhh[(u * 3 + 2) * 16 + colq];
@@ -347,8 +368,8 @@ __global__ __launch_bounds__(64) void gru_small_kernel(GruSmallArgs g) {
         const f32x2 vbr = {br, br}, vbz = {bz, bz}, vbn = {bn, bn};
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            const f32x2 ar = {acch[0][2 * p], acch[0][2 * p + 1]}, az = {acch[1][2 * p], acch[1][2 * p + 1]},
-                        an = {acch[2][2 * p], acch[2][2 * p + 1]};
+            const f32x2 ar = {gh[0][2 * p], gh[0][2 * p + 1]}, az = {gh[1][2 * p], gh[1][2 * p + 1]},
+                        an = {gh[2][2 * p], gh[2][2 * p + 1]};
             const f32x2 xr = {gin[0][2 * p], gin[0][2 * p + 1]}, xz = {gin[1][2 * p], gin[1][2 * p + 1]},
                         xn = {gin[2][2 * p], gin[2][2 * p + 1]};
             const f32x2 r = fast_sigmoid2(xr + (ar + vbr));
@@ -362,9 +383,9 @@ __global__ __launch_bounds__(64) void gru_small_kernel(GruSmallArgs g) {
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float r = kns_sigmoid(gin[0][i] + (acch[0][i] + br));
-            float z = kns_sigmoid(gin[1][i] + (acch[1][i] + bz));
-            float n = kns_tanh(__builtin_fmaf(r, acch[2][i] + bn, gin[2][i]));
+            float r = kns_sigmoid(gin[0][i] + (gh[0][i] + br));
+            float z = kns_sigmoid(gin[1][i] + (gh[1][i] + bz));
+            float n = kns_tanh(__builtin_fmaf(r, gh[2][i] + bn, gin[2][i]));
             hnew[i] = __builtin_fmaf(z, hown[i] - n, n);
         }
     }
@@ -378,9 +399,9 @@ __global__ __launch_bounds__(64) void gru_small_kernel(GruSmallArgs g) {
 void launch_gru_small(const GruSmallArgs &a, hipStream_t s) {
     dim3 grid(kUnitTiles, a.mtiles);
     if (a.precision == kBf16)
-        hipLaunchKernelGGL(gru_small_kernel<PBF16>, grid, dim3(64), 0, s, a);
+        hipLaunchKernelGGL(gru_small_kernel<PBF16>, grid, dim3(192), 0, s, a);
     else
-        hipLaunchKernelGGL(gru_small_kernel<PF32>, grid, dim3(64), 0, s, a);
+        hipLaunchKernelGGL(gru_small_kernel<PF32>, grid, dim3(192), 0, s, a);
 }
 
 // ---- 8-wave form of the resident recurrent kernel.  Measured on MI355X: a single wave per SIMD executes its MFMAs and
