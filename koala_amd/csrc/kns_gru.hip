@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, 1) void gru_resident_kernel(GruArgs g) {
 template <class P>
 __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
     // One workgroup per (unit tile, m-tile), one wave per gate: each wave streams only its gate's weights (a third of the
-    // tile's), four k-blocks of operands requested before the four MFMAs that use them; the three accumulator pairs meet
+    // tile's), eight k-blocks of operands requested before the MFMAs that use them; the three accumulator pairs meet
     // in LDS and wave 0 does the gate math.  Every accumulator still sums its k-blocks in ascending order, so the result is
     // bit-identical to the chunked kernels.
     typedef typename P::frag_t frag_t;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
     const frag_t *a0 = (const frag_t *) g.a0 + (size_t) mt * g.nb0 * 64 + lane;
     const frag_t *a1 = (const frag_t *) g.a1 + (size_t) mt * NBH * 64 + lane;
     f32x4 acci = f32x4{0.f, 0.f, 0.f, 0.f}, acch = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int kAhead = 4;
+    constexpr int kAhead = 8;
     for (int b0 = 0; b0 < nb; b0 += kAhead) {
         frag_t a[kAhead], w[kAhead];
 #pragma unroll
