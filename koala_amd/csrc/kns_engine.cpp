@@ -707,14 +707,17 @@ bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err) 
         return process_host_pipelined(T, pcm, out, kin == kPtrPinned && kout == kPtrPinned, err);
     memcpy(h_in_, pcm, bytes);
     if (T == 1 && use_graph_ && stream_ == own_stream_ && !profiling_) {
-        // frame-by-frame streaming: copy-in, the 23 kernels and copy-out replayed as one hipGraph
+        // frame-by-frame streaming: (copy-in,) the kernels of one frame (and copy-out) replayed as one hipGraph
         const int parity = hs_cur_;
         if (!frame_graph_[parity]) {
             hipGraph_t graph = nullptr;
             if (hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal) != hipSuccess) goto fail;
-            bool ok = hipMemcpyAsync(d_in_, h_in_, bytes, hipMemcpyHostToDevice, stream_) == hipSuccess;
-            ok = ok && run_device(1, d_in_, d_out_, err);
-            ok = ok && hipMemcpyAsync(h_out_, d_out_, bytes, hipMemcpyDeviceToHost, stream_) == hipSuccess;
+            // small batches: the analysis kernel reads the frame from, and the synthesis kernel writes it to, the pinned
+            // host staging buffers directly (device-visible memory): two copy nodes of ~4 us each less per frame
+            const bool zero_copy = bytes <= 64 * 1024 && getenv("KOALA_AMD_NO_ZERO_COPY") == nullptr;
+            bool ok = zero_copy || hipMemcpyAsync(d_in_, h_in_, bytes, hipMemcpyHostToDevice, stream_) == hipSuccess;
+            ok = ok && run_device(1, zero_copy ? h_in_ : d_in_, zero_copy ? h_out_ : d_out_, err);
+            ok = ok && (zero_copy || hipMemcpyAsync(h_out_, d_out_, bytes, hipMemcpyDeviceToHost, stream_) == hipSuccess);
             if (hipStreamEndCapture(stream_, &graph) != hipSuccess || !ok) goto fail;
             if (hipGraphInstantiate(&frame_graph_[parity], graph, nullptr, nullptr, 0) != hipSuccess) goto fail;
             (void) hipGraphDestroy(graph);
