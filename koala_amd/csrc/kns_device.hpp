@@ -273,7 +273,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, un
     return __builtin_amdgcn_make_buffer_rsrc((void *) base, 0, bytes, 0x00020000);
 }
 __device__ __forceinline__ bf16x8 buf_load_frag(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 // 16-byte buffer stores take NO scalar offset here (fold it into the descriptor's base): with one, gfx950 reads the
