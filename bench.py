@@ -139,15 +139,22 @@ def main():
     stages = {}
     dev_ms = sum(v['ms'] for v in prof.values()) / prof_steps
     for name, (bound, per_launch, launches) in work.items():
-        ms = prof[name]['ms'] / max(1, prof[name]['launches'])
+        n = prof[name]['launches']
+        if n == 0:  # e.g. small batches: the input GEMMs run inside the frame-by-frame recurrent launches
+            continue
+        actual = n / float(prof_steps)  # launches per step as measured (small batches step the layers frame by frame)
+        per_launch = per_launch * launches / actual
+        if name == 'gru_recurrent' and prof['gemm_input']['launches'] == 0:
+            per_launch += 2.0 * MAC_GEMM_IN * frames_per_launch / actual
+        ms = prof[name]['ms'] / n
         if bound == 'hbm':
             achieved, peak, unit = per_launch / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s'
         else:
             achieved, peak, unit = per_launch / (ms * 1e-3) / 1e12, MFMA_PEAK_TFLOPS[args.precision], 'TFLOP/s'
         stages[name] = {'bound': bound, 'achieved': round(achieved, 3), 'peak': peak, 'unit': unit,
                         'frac': round(achieved / peak, 5), 'avg_launch_ms': round(ms, 5),
-                        'launches_per_step': launches,
-                        'share_of_device_time': round(ms * launches / dev_ms, 4) if dev_ms else None}
+                        'launches_per_step': round(actual, 2) if actual != int(actual) else int(actual),
+                        'share_of_device_time': round(ms * actual / dev_ms, 4) if dev_ms else None}
     dominant = max(stages, key=lambda k: stages[k]['avg_launch_ms'] * stages[k]['launches_per_step'])
     roofline = dict(stages[dominant])
     roofline['kernel'] = dominant

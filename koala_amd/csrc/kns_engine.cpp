@@ -522,18 +522,24 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
 
     // one frame of a few m-tiles: latency matters, not throughput -- whole GRU layers as single wide launches
     const bool small = T == 1 && mtb <= 16 && getenv("KOALA_AMD_NO_SMALL") == nullptr;
+    // A few m-tiles (<= 256 streams): the chunked recurrent kernels would occupy mtb workgroups, so the layers run frame
+    // by frame through the low-latency kernel instead (17 x mtb workgroups of three waves per frame, input GEMM included):
+    // at 256 streams x 32 frames 8 x 32 launches of ~8 us beat 8 x (0.1 + 0.75) ms.  Frame t of a call reads the hidden
+    // state from ping-pong buffer (hs_cur_ + t) & 1 and writes the other one.
+    const bool small_steps = T > 1 && mtb <= 16 && getenv("KOALA_AMD_NO_SMALL") == nullptr;
     auto gru_small = [&](const void *a0, int nb0, const void *a1, const void *wih, const float *bih, const void *whh,
-                         const float *bhh, int layer, void *hseq) {
+                         const float *bhh, int layer, void *hseq, int t = 0) {
         GruSmallArgs g;
-        g.a0 = a0;
-        g.a1 = a1;
+        const size_t frame = (size_t) t * mtb * 1024;  // bytes of one k-block column of A per frame
+        g.a0 = a0 ? (const char *) a0 + frame * nb0 : nullptr;
+        g.a1 = (const char *) a1 + frame * nbh_;
         g.wih = wih;
         g.bih = bih;
         g.whh = whh;
         g.bhh = bhh;
-        g.hstate_in = d_hstate_[hs_cur_] + (size_t) layer * mtb * kUnitTiles * 256;
-        g.hstate_out = d_hstate_[hs_cur_ ^ 1] + (size_t) layer * mtb * kUnitTiles * 256;
-        g.hseq = hseq;
+        g.hstate_in = d_hstate_[(hs_cur_ + t) & 1] + (size_t) layer * mtb * kUnitTiles * 256;
+        g.hstate_out = d_hstate_[(hs_cur_ + t + 1) & 1] + (size_t) layer * mtb * kUnitTiles * 256;
+        g.hseq = (char *) hseq + frame * nbh_;
         g.nb0 = nb0;
         g.mtiles = mtb;
         g.precision = prec_;
@@ -551,6 +557,10 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         if (small) {
             gru_small(yprev, nby, d_e_, d.w_ih_a, d.b_ih_a, d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_);
             gru_small(nullptr, 0, d_hseq_a_, d.w_ih_b, d.b_ih_b, d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_);
+        } else if (small_steps) {
+            for (int t = 0; t < T; ++t) gru_small(yprev, nby, d_e_, d.w_ih_a, d.b_ih_a, d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_, t);
+            for (int t = 0; t < T; ++t)
+                gru_small(nullptr, 0, d_hseq_a_, d.w_ih_b, d.b_ih_b, d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_, t);
         } else {
             gemm(kClsGemmIn, yprev, nby, d_e_, nbh_, d.w_ih_a, d.b_ih_a, d_gi_, kGateTiles, 3 * kHidden, kOutGi);
             gru(d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_);
@@ -574,7 +584,10 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     static const int seg_env = getenv("KOALA_AMD_SYNTH_SEG") ? atoi(getenv("KOALA_AMD_SYNTH_SEG")) : 0;
     // two segments per stream tile (512 workgroups at B = 4096) measured best: fewer, longer segments amortise the
     // one replayed frame; a single segment leaves half the chip without a second workgroup to overlap with
-    const int seg = seg_env > 0 ? seg_env : (T <= 4 ? T : (T + 1) / 2 > 4 ? (T + 1) / 2 : 4);
+    // ... and with few stream tiles the segments shrink (down to 4 frames) until there are about two workgroups per CU
+    int seg_auto = T <= 4 ? T : ((T + 1) / 2 > 4 ? (T + 1) / 2 : 4);
+    while (seg_auto > 4 && mtb * ((T + seg_auto - 1) / seg_auto) < 512) seg_auto = seg_auto / 2 > 4 ? seg_auto / 2 : 4;
+    const int seg = seg_env > 0 ? seg_env : seg_auto;
     sy.seg = T <= seg ? T : seg;
     sy.out = d_out;
     sy.B = B_;
@@ -583,7 +596,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     tick(kClsSynthesis);
     if (only < 0 || only == kClsSynthesis) launch_synthesis(sy, stream_);
     tock(kClsSynthesis);
-    hs_cur_ ^= 1;
+    hs_cur_ = small_steps ? (hs_cur_ + T) & 1 : hs_cur_ ^ 1;
     if (!in_place) tail_cur_ ^= 1;
 
     hipError_t e = hipGetLastError();
