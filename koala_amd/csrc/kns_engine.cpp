@@ -522,11 +522,12 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
 
     // one frame of a few m-tiles: latency matters, not throughput -- whole GRU layers as single wide launches
     const bool small = T == 1 && mtb <= 16 && getenv("KOALA_AMD_NO_SMALL") == nullptr;
-    // A few m-tiles (<= 256 streams): the chunked recurrent kernels would occupy mtb workgroups, so the layers run frame
+    // Fewer than 256 m-tiles: the chunked recurrent kernels would occupy mtb workgroups, so the layers run frame
     // by frame through the low-latency kernel instead (17 x mtb workgroups of three waves per frame, input GEMM included):
-    // in fp32 at 256 streams x 32 frames 8 x 32 launches of ~13 us beat 8 x (0.1 + 0.75) ms.  Frame t of a call reads the hidden
+    // in fp32 at 256 streams x 32 frames 8 x 32 launches of ~13 us beat 8 x (0.1 + 0.75) ms (2.8 vs 1.2 M frames/s; 5.5 vs
+    // 3.7 M at 1024 streams, 7.2 vs 6.7 M at 3072, equal at 4096).  Frame t of a call reads the hidden
     // state from ping-pong buffer (hs_cur_ + t) & 1 and writes the other one.
-    static const int steps_mt = getenv("KOALA_AMD_STEPS_MT") ? atoi(getenv("KOALA_AMD_STEPS_MT")) : 16;  // tuning switch
+    static const int steps_mt = getenv("KOALA_AMD_STEPS_MT") ? atoi(getenv("KOALA_AMD_STEPS_MT")) : 192;  // tuning switch
     // (fp32 only: the bf16 recurrent kernel keeps its weights on chip and is faster than 8 us per frame and layer even
     // with 16 workgroups -- 11.3 vs 5.2 M frames/s at 256 streams; the fp32 one streams them: 1.2 vs 2.8 M)
     const bool small_steps = T > 1 && mtb <= steps_mt && prec_ != kBf16 && getenv("KOALA_AMD_NO_SMALL") == nullptr;
