@@ -725,7 +725,11 @@ bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err) 
     memcpy(h_in_, pcm, bytes);
     if (T == 1 && use_graph_ && stream_ == own_stream_ && !profiling_) {
         // frame-by-frame streaming: (copy-in,) the kernels of one frame (and copy-out) replayed as one hipGraph
-        const int parity = hs_cur_;
+        // A captured frame has the state buffers it reads and writes baked in: one graph per combination of the three
+        // ping-pong indices.  (A single-frame call leaves history and tail in place and flips the hidden state only, but
+        // multi-frame calls in between flip the other two as well.)
+        const int hs = hs_cur_;
+        const int parity = hs | (hist_cur_ << 1) | (tail_cur_ << 2);
         if (!frame_graph_[parity]) {
             hipGraph_t graph = nullptr;
             if (hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal) != hipSuccess) goto fail;
@@ -738,10 +742,10 @@ bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err) 
             if (hipStreamEndCapture(stream_, &graph) != hipSuccess || !ok) goto fail;
             if (hipGraphInstantiate(&frame_graph_[parity], graph, nullptr, nullptr, 0) != hipSuccess) goto fail;
             (void) hipGraphDestroy(graph);
-            hs_cur_ = parity;  // the capture only recorded the launches; run_device's bookkeeping is replayed below
+            hs_cur_ = hs;  // the capture only recorded the launches; run_device's bookkeeping is replayed below
         }
         if (hipGraphLaunch(frame_graph_[parity], stream_) != hipSuccess) goto fail;
-        hs_cur_ = parity ^ 1;
+        hs_cur_ = hs ^ 1;
         if (hipStreamSynchronize(stream_) != hipSuccess) goto fail;
         memcpy(out, h_out_, bytes);
         return true;

@@ -98,7 +98,7 @@ private:
     size_t host_pipeline_min_bytes_ = 0;
 
     // hipGraph of one host-pointer frame (copy-in, 23 kernels, copy-out); built on first use
-    hipGraphExec_t frame_graph_[2] = {nullptr, nullptr};  // one per parity of the hidden-state ping-pong
+    hipGraphExec_t frame_graph_[8] = {};  // one per combination of the hidden-state / history / tail ping-pong indices
     bool use_graph_ = true;
 
     // profiling

@@ -283,3 +283,40 @@ def test_alternative_kernels_give_identical_pcm(random_model):
         assert out.returncode == 0, (switch, out.stderr[-2000:])
         digests[switch] = [ln for ln in out.stdout.splitlines() if ln.startswith('DIGEST')][-1]
     assert len(set(digests.values())) == 1, digests
+
+
+@pytest.mark.parametrize('precision,B,Tmax', [('fp32', 21, 6), ('bf16', 21, 6), ('fp32', 290, 4)])
+def test_random_call_sequences_keep_the_stream_state_straight(random_model, precision, B, Tmax):
+    """A soak over the state bookkeeping (history / overlap-add / hidden-state ping-pong buffers, the single-frame graph,
+    the frame-by-frame fp32 path, masked resets): random chunk lengths, host and device pointers, random per-stream resets --
+    the engine must track the oracle, which is driven through the same sequence, call by call."""
+    torch = pytest.importorskip('torch')
+    rng = np.random.default_rng(42)
+    prec = oracle.PREC_BF16 if precision == 'bf16' else oracle.PREC_FP32
+    tol = 6 if precision == 'bf16' else 1
+    kb = koala_amd.create_batch('key', B, Tmax, precision, model_path=random_model)
+    ref = oracle.Oracle(random_model, B, prec)
+    worst = 0
+    for call in range(24):
+        T = int(rng.integers(1, Tmax + 1))
+        x = synth_streams(B, T, seed=1000 + call)
+        if call % 7 == 3:
+            mask = (rng.random(B) < 0.3).astype(np.uint8)
+            kb.reset(mask)
+            ref.reset(mask)
+        elif call == 12:
+            kb.reset()
+            ref.reset()
+        if call % 3 == 0:
+            dx = torch.from_numpy(x).cuda()
+            dy = torch.zeros_like(dx)
+            torch.cuda.synchronize()
+            kb.process_device(T, dx.data_ptr(), dy.data_ptr())
+            kb.synchronize()
+            y = dy.cpu().numpy()
+        else:
+            y = kb.process(x)
+        want = ref.process(x)
+        worst = max(worst, int(lsb(y, want).max()))
+        assert lsb(y, want).max() <= tol, (call, T)
+    kb.delete()
