@@ -285,8 +285,9 @@ def test_alternative_kernels_give_identical_pcm(random_model):
     assert len(set(digests.values())) == 1, digests
 
 
-@pytest.mark.parametrize('precision,B,Tmax', [('fp32', 21, 6), ('bf16', 21, 6), ('fp32', 290, 4)])
-def test_random_call_sequences_keep_the_stream_state_straight(random_model, precision, B, Tmax):
+@pytest.mark.parametrize('precision,B,Tmax,calls', [('fp32', 21, 6, 24), ('bf16', 21, 6, 24), ('fp32', 290, 4, 24),
+                                                    ('bf16', 4096, 4, 10), ('bf16', 4100, 3, 8), ('fp32', 4096, 2, 6)])
+def test_random_call_sequences_keep_the_stream_state_straight(random_model, precision, B, Tmax, calls):
     """A soak over the state bookkeeping (history / overlap-add / hidden-state ping-pong buffers, the single-frame graph,
     the frame-by-frame fp32 path, masked resets): random chunk lengths, host and device pointers, random per-stream resets --
     the engine must track the oracle, which is driven through the same sequence, call by call."""
@@ -297,14 +298,14 @@ def test_random_call_sequences_keep_the_stream_state_straight(random_model, prec
     kb = koala_amd.create_batch('key', B, Tmax, precision, model_path=random_model)
     ref = oracle.Oracle(random_model, B, prec)
     worst = 0
-    for call in range(24):
+    for call in range(calls):
         T = int(rng.integers(1, Tmax + 1))
         x = synth_streams(B, T, seed=1000 + call)
         if call % 7 == 3:
             mask = (rng.random(B) < 0.3).astype(np.uint8)
             kb.reset(mask)
             ref.reset(mask)
-        elif call == 12:
+        elif call == calls // 2:
             kb.reset()
             ref.reset()
         if call % 3 == 0:
