@@ -321,3 +321,20 @@ def test_random_call_sequences_keep_the_stream_state_straight(random_model, prec
         worst = max(worst, int(lsb(y, want).max()))
         assert lsb(y, want).max() <= tol, (call, T)
     kb.delete()
+
+
+@pytest.mark.parametrize('precision,B,T', [('fp32', 48, 37), ('bf16', 48, 37), ('bf16', 300, 19), ('fp32', 16, 64),
+                                           ('bf16', 1040, 9)])
+def test_long_chunks_of_small_and_odd_batches(random_model, precision, B, T):
+    """Odd frame counts and small or ragged batches in ONE call: the synthesis kernel's time segments (each replays a frame
+    to rebuild its overlap-add tail, and they shrink with the stream count), the frame-by-frame fp32 layers and the
+    fallback GEMMs all see shapes the throughput configuration never produces."""
+    x = synth_streams(B, T, seed=77)
+    kb = koala_amd.create_batch('key', B, T, precision, model_path=random_model)
+    y = kb.process(x)
+    y2 = kb.process(x)  # a second call continues the streams
+    kb.delete()
+    ref = oracle.Oracle(random_model, B, oracle.PREC_BF16 if precision == 'bf16' else oracle.PREC_FP32)
+    want, want2 = ref.process(x), ref.process(x)
+    tol = 6 if precision == 'bf16' else 1
+    assert lsb(y, want).max() <= tol and lsb(y2, want2).max() <= tol
