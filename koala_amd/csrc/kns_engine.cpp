@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <thread>
 
 namespace kns {
@@ -173,13 +174,17 @@ void *Engine::dalloc(size_t bytes, bool zero) {
         return nullptr;
     }
     allocs_.push_back(p);
-    if (zero) (void) hipMemset(p, 0, bytes);
+    // (on the handle's own non-blocking stream: a legacy-stream operation would collide with another handle's graph capture)
+    if (zero) (void) hipMemsetAsync(p, 0, bytes, own_stream_);
     return p;
 }
 
 void *Engine::upload(const void *src, size_t bytes) {
     void *p = dalloc(bytes, false);
-    if (p) (void) hipMemcpy(p, src, bytes, hipMemcpyHostToDevice);
+    if (p) {
+        (void) hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, own_stream_);
+        (void) hipStreamSynchronize(own_stream_);  // `src` is usually a temporary
+    }
     return p;
 }
 
@@ -334,7 +339,7 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
         *err = "Failed to allocate pinned host memory.";
         return false;
     }
-    if (hipDeviceSynchronize() != hipSuccess) {
+    if (hipStreamSynchronize(own_stream_) != hipSuccess) {
         *err = std::string("Device initialisation failed: ") + hipGetErrorString(hipGetLastError());
         return false;
     }
@@ -611,6 +616,8 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     return true;
 }
 
+static std::mutex g_capture_mutex;
+
 enum PointerKind { kPtrPageable = 0, kPtrPinned = 1, kPtrDevice = 2 };
 
 static PointerKind pointer_kind(const void *p) {
@@ -732,7 +739,10 @@ bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err) 
         const int parity = hs | (hist_cur_ << 1) | (tail_cur_ << 2);
         if (!frame_graph_[parity]) {
             hipGraph_t graph = nullptr;
-            if (hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal) != hipSuccess) goto fail;
+            // (relaxed mode and one capture at a time in the process: other threads -- other handles being created, the
+            // host application -- may touch the legacy stream meanwhile, which would invalidate a stricter capture)
+            std::lock_guard<std::mutex> capture_lock(g_capture_mutex);
+            if (hipStreamBeginCapture(stream_, hipStreamCaptureModeRelaxed) != hipSuccess) goto fail;
             // small batches: the analysis kernel reads the frame from, and the synthesis kernel writes it to, the pinned
             // host staging buffers directly (device-visible memory): two copy nodes of ~4 us each less per frame
             const bool zero_copy = bytes <= 64 * 1024 && getenv("KOALA_AMD_NO_ZERO_COPY") == nullptr;
@@ -779,7 +789,8 @@ int64_t Engine::debug_read(int what, float *out, int64_t capacity, std::string *
     const int T = last_T_, mtb = Bpad_ / 16;
     auto fetch = [&](const void *d, size_t bytes) {
         std::vector<uint8_t> h(bytes);
-        (void) hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost);
+        (void) hipMemcpyAsync(h.data(), d, bytes, hipMemcpyDeviceToHost, stream_);
+        (void) hipStreamSynchronize(stream_);
         return h;
     };
     // logical element (row r of m-tile, k) of an A-packed buffer with nb blocks per m-tile

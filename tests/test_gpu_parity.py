@@ -338,3 +338,39 @@ def test_long_chunks_of_small_and_odd_batches(random_model, precision, B, T):
     want, want2 = ref.process(x), ref.process(x)
     tol = 6 if precision == 'bf16' else 1
     assert lsb(y, want).max() <= tol and lsb(y2, want2).max() <= tol
+
+
+def test_distinct_handles_on_distinct_threads(random_model):
+    """The threading contract of DESIGN.md section 1: a handle has one caller at a time, distinct handles are independent
+    -- here four of them (single-stream graph path and batch path, both precisions) run concurrently from four threads."""
+    import threading
+    x = synth_streams(24, 40, seed=11)
+    want = {p: oracle.Oracle(random_model, 24, oracle.PREC_BF16 if p == 'bf16' else oracle.PREC_FP32).process(x)
+            for p in ('fp32', 'bf16')}
+    results, errors = {}, []
+
+    def batch_worker(name, precision):
+        try:
+            kb = koala_amd.create_batch('key', 24, 8, precision, model_path=random_model)
+            results[name] = np.concatenate([kb.process(np.ascontiguousarray(x[:, c * 2048:(c + 1) * 2048])) for c in range(5)], axis=1)
+            kb.delete()
+        except Exception as e:  # noqa: BLE001
+            errors.append((name, repr(e), getattr(e, 'message_stack', None)))
+
+    def single_worker(name, stream):
+        try:
+            k = koala_amd.create('key', model_path=random_model)
+            results[name] = np.concatenate([np.array(k.process(x[stream, f * 256:(f + 1) * 256]), np.int16) for f in range(40)])
+            k.delete()
+        except Exception as e:  # noqa: BLE001
+            errors.append((name, repr(e), getattr(e, 'message_stack', None)))
+
+    threads = [threading.Thread(target=batch_worker, args=('b32', 'fp32')), threading.Thread(target=batch_worker, args=('b16', 'bf16')),
+               threading.Thread(target=single_worker, args=('s0', 0)), threading.Thread(target=single_worker, args=('s5', 5))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert lsb(results['b32'], want['fp32']).max() <= 1 and lsb(results['b16'], want['bf16']).max() <= 6
+    assert lsb(results['s0'], want['fp32'][0]).max() <= 1 and lsb(results['s5'], want['fp32'][5]).max() <= 1
