@@ -374,3 +374,24 @@ def test_distinct_handles_on_distinct_threads(random_model):
     assert not errors, errors
     assert lsb(results['b32'], want['fp32']).max() <= 1 and lsb(results['b16'], want['bf16']).max() <= 6
     assert lsb(results['s0'], want['fp32'][0]).max() <= 1 and lsb(results['s5'], want['fp32'][5]).max() <= 1
+
+
+@pytest.mark.parametrize('precision,B,T', [('bf16', 32768, 16), ('bf16', 20000, 8), ('fp32', 12288, 4)])
+def test_batches_far_beyond_the_bench_size(random_model, precision, B, T):
+    """Eight times the bench batch (and sizes that are no multiple of anything): 64-bit addressing of every workspace, the
+    GEMM stage arithmetic at other m-tile counts.  64 inputs are replicated over all slots; slot 0..63 is checked against
+    the oracle and every replica must equal it bit for bit."""
+    base = synth_streams(64, 2 * T, seed=123)
+    reps = (B + 63) // 64
+    kb = koala_amd.create_batch('key', B, T, precision, model_path=random_model)
+    ref = oracle.Oracle(random_model, 64, oracle.PREC_BF16 if precision == 'bf16' else oracle.PREC_FP32)
+    for c in range(2):
+        chunk = np.ascontiguousarray(base[:, c * T * 256:(c + 1) * T * 256])
+        y = kb.process(np.tile(chunk, (reps, 1))[:B])
+        want = ref.process(chunk)
+        assert lsb(y[:64], want).max() <= (6 if precision == 'bf16' else 1)
+        full = (B // 64) * 64
+        assert np.array_equal(y[:full].reshape(B // 64, 64, -1), np.broadcast_to(y[:64], (B // 64, 64, y.shape[1])))
+        if B > full:
+            assert np.array_equal(y[full:], y[:B - full])
+    kb.delete()
