@@ -395,3 +395,34 @@ def test_batches_far_beyond_the_bench_size(random_model, precision, B, T):
         if B > full:
             assert np.array_equal(y[full:], y[:B - full])
     kb.delete()
+
+
+def test_handles_release_what_they_hold(random_model):
+    """Create / use / delete in a loop (single-stream and batch handles, both call paths): device memory must come back --
+    buffers, streams, events and captured graphs are all owned by the handle."""
+    torch = pytest.importorskip('torch')
+    x = synth_streams(64, 4, seed=3)
+    frame = x[0, :256]
+
+    def cycle():
+        k = koala_amd.create('key', model_path=random_model)
+        k.process(frame)
+        k.process(frame)
+        k.delete()
+        kb = koala_amd.create_batch('key', 64, 4, 'bf16', model_path=random_model)
+        kb.process(x)
+        kb.process(np.ascontiguousarray(x[:, :256]))
+        pin = kb.alloc_host(4)
+        pin[:] = x
+        kb.process_into(pin, kb.alloc_host(4))
+        kb.delete()
+
+    for _ in range(3):
+        cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(25):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, 'device memory shrank by %d MiB over 25 create/delete cycles' % ((free0 - free1) >> 20)
