@@ -426,3 +426,20 @@ def test_handles_release_what_they_hold(random_model):
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 64 << 20, 'device memory shrank by %d MiB over 25 create/delete cycles' % ((free0 - free1) >> 20)
+
+
+def test_host_calls_on_a_caller_stream(random_model):
+    """`set_stream` + host pointers: the pipelined path computes on the caller's stream (its copy streams hang off it by
+    events) and single-frame calls fall back from the graph to plain launches; results as on the handle's own stream."""
+    torch = pytest.importorskip('torch')
+    B, T = 4096, 32
+    x = np.tile(synth_streams(64, T + 1, seed=21), (B // 64, 1))
+    kb = koala_amd.create_batch('key', B, T, 'bf16', model_path=random_model)
+    own = [kb.process(np.ascontiguousarray(x[:, :T * 256])), kb.process(np.ascontiguousarray(x[:, T * 256:]))]
+    kb.reset()
+    s = torch.cuda.Stream()
+    kb.set_stream(s.cuda_stream)
+    mine = [kb.process(np.ascontiguousarray(x[:, :T * 256])), kb.process(np.ascontiguousarray(x[:, T * 256:]))]
+    kb.set_stream(0)
+    kb.delete()
+    assert np.array_equal(own[0], mine[0]) and np.array_equal(own[1], mine[1])
