@@ -410,20 +410,24 @@ void launch_gru_small(const GruSmallArgs &a, hipStream_t s) {
 // tile w entirely in VGPRs (27 fragments), the first 14 fragments of tile w + 8 in VGPRs and its last 13 in LDS, tile 16
 // in LDS: 328 KiB of registers + 131 KiB of LDS.  A fragments are re-read from LDS per k-block.
 constexpr int kR8Waves = 8;
+#ifndef R8C_Q
+#define R8C_Q 3
+#endif
 constexpr int kR8RegFrags1 = 14;                      // fragments of the second tile kept in registers
 constexpr int kR8LdsFrags1 = 27 - kR8RegFrags1;       // ... and in LDS
 constexpr int kR8Lds = 2 * PBF16::NBH * 1024 + kR8Waves * kR8LdsFrags1 * 1024 + 27 * 1024 + kResBiasBytes;
 
 // MFMAs of one unit tile whose fragments [first_lds, 27) live in LDS at wl[(i - first_lds)] (i = k_block * 3 + gate) and
 // the rest in wreg[i]; LDS fragments go through a kQ-deep register queue
-template <int kFirstLds, int kQ, int kNReg>
+template <int kFirstLds, int kQ, int kNReg, bool kChain = false>
 __device__ __forceinline__ void r8_tile_mma(f32x4 (&acc)[3], const bf16x8 *ha, const bf16x8 (&wreg)[kNReg], const bf16x8 *wl,
-                                            int lane) {
+                                            int lane, f32x4 *a16 = nullptr, const bf16x8 *w16 = nullptr) {
     constexpr int N = 27;
-    bf16x8 qb[kQ];
+    bf16x8 qb[kQ], qc;
 #pragma unroll
     for (int p = 0; p < kQ; ++p)
         if (kFirstLds + p < N) qb[p] = wl[p * 64 + lane];
+    if (kChain) qc = w16[0];
     bf16x8 a = ha[lane];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -437,6 +441,11 @@ __device__ __forceinline__ void r8_tile_mma(f32x4 (&acc)[3], const bf16x8 *ha, c
             if (i + kQ < N) qb[j % kQ] = wl[(j + kQ) * 64 + lane];
         }
         acc[i % 3] = PBF16::mma(a, b, acc[i % 3]);
+        if (kChain && i % 3 == 2) {  // one link of unit tile 16's k chain per k-block, same A fragment
+            const bf16x8 c = qc;
+            if (i / 3 + 1 < PBF16::NBH) qc = w16[(i / 3 + 1) * 3 * 64];
+            *a16 = PBF16::mma(a, c, *a16);
+        }
     }
 }
 
@@ -463,9 +472,10 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     const int u0 = wave, u1 = wave + 8, u2 = 16;
     // Unit tile 16 (the 17th) would make one wave's serial chain 3 tiles long while the others wait at the barrier.
     // The first wave of each SIMD gets the SIMD's issue slots first and is through its two tiles ~1 000 cycles before its
-    // partner (per-wave stamps, tools/timing.py), so tile 16 is done in that slack: waves 1, 2, 3 run its 27 MFMAs (one
-    // gate each, the full k chain in one accumulator, so the arithmetic is unchanged), the accumulators cross LDS behind a
-    // step-count flag, and waves 0..3 each do the gate math of one of the four rows a lane owns.  One barrier per step.
+    // partner (per-wave stamps, tools/timing.py), so tile 16 is done in that slack: waves 1, 2, 3 carry its 27 MFMAs (one
+    // gate each, the full k chain in one accumulator, so the arithmetic is unchanged) through their second tile's k loop
+    // as a fourth accumulator, the accumulators cross LDS behind a step-count flag, and waves 0..3 each do the gate math of
+    // one of the four rows a lane owns.  One barrier per step.
     const int g16 = wave - 1;         // gate whose tile-16 MFMAs this wave computes (waves 1..3)
     const bool c16 = wave >= 1 && wave <= 3;
     const bool q16 = wave < 4;        // this wave finishes row (lane >> 4) * 4 + wave of tile 16
@@ -584,26 +594,18 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
         KNS_STAMP(3);
 #pragma unroll
         for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        r8_tile_mma<kR8RegFrags1, 3, kR8RegFrags1>(acc, ha, w1, wl1w, lane);
-        KNS_STAMP(4);
-        gates(1, u1, acc);
-        KNS_STAMP(5);
-        if (c16) {  // waves 1, 2, 3: one gate of unit tile 16, k-blocks in order in one accumulator
+        if (c16) {  // waves 1, 2, 3 also carry one gate of unit tile 16 (k-blocks in order in one accumulator) through this loop
             f32x4 a16 = f32x4{0.f, 0.f, 0.f, 0.f};
-            frag_t qb[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) qb[p] = wl16[(p * 3 + g16) * 64 + lane];
-#pragma unroll
-            for (int blk = 0; blk < NBH; ++blk) {
-                const frag_t a = ha[blk * 64 + lane];
-                const frag_t b = qb[blk % 3];
-                if (blk + 3 < NBH) qb[blk % 3] = wl16[((blk + 3) * 3 + g16) * 64 + lane];
-                a16 = P::mma(a, b, a16);
-            }
+            r8_tile_mma<kR8RegFrags1, R8C_Q, kR8RegFrags1, true>(acc, ha, w1, wl1w, lane, &a16, wl16 + g16 * 64 + lane);
             acc16[g16 * 64 + lane] = a16;
             // LDS operations of one wave complete in order: whoever sees the flag sees the accumulators
             asm volatile("ds_write_b32 %0, %1" ::"v"(flag16 + g16 * 4), "v"(t + 1) : "memory");
+        } else {
+            r8_tile_mma<kR8RegFrags1, 3, kR8RegFrags1>(acc, ha, w1, wl1w, lane);
         }
+        KNS_STAMP(4);
+        gates(1, u1, acc);
+        KNS_STAMP(5);
         KNS_STAMP(6);
         {  // (requested by every wave, used by waves 0..3)
             const float xr = (float) gi16[0][e16], xz = (float) gi16[1][e16], xn = (float) gi16[2][e16];
