@@ -195,3 +195,36 @@ def test_stream_demo_matches_the_frame_loop(gate_model, tmp_path):
     k.delete()
     assert np.array_equal(samples(out1), want) and np.array_equal(samples(out2), want)
     assert np.array_equal(samples(ref1), padded)
+
+
+def test_c_host_binds_the_library_like_the_reference_c_demo(gate_model, tmp_path):
+    """koala_amd/demo/c/koala_file_demo.c: a plain-C host that dlopen()s libpv_koala.so and dlsym()s the pv_koala.h entry
+    points (what the reference's demo/c/koala_demo_file.c:262-340 binds) -- no Python, no torch in the process.  Its
+    delay-compensated output must equal the Python surface's sample for sample, single-stream and through the batch ABI."""
+    import shutil
+    import subprocess
+    import wave
+    from conftest import GOLDEN, ROOT
+    from koala_amd._util import default_library_path
+    from koala_amd.demo.koala_demo_file import enhance_single, read_wav
+    gcc = shutil.which('gcc')
+    if not gcc:
+        pytest.skip('gcc not available')
+    exe = tmp_path / 'koala_file_demo'
+    subprocess.check_call([gcc, '-O2', '-o', str(exe), ROOT + '/koala_amd/demo/c/koala_file_demo.c', '-ldl'])
+    out1, out2 = tmp_path / 'c1.wav', tmp_path / 'c2.wav'
+    base = [str(exe), '-l', default_library_path(), '-m', gate_model, '-i', GOLDEN + '/test.wav']
+    r = subprocess.run(base + ['-o', str(out1)], capture_output=True, text=True)
+    assert r.returncode == 0 and 'real time factor' in r.stdout, r.stderr
+    r = subprocess.run(base + ['-o', str(out2), '--streams', '20', '--frames', '8'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run(base[:3] + ['-m', '/nonexistent.kns', '-i', GOLDEN + '/test.wav', '-o', str(out1)], capture_output=True, text=True)
+    assert r.returncode == 1 and 'IO_ERROR' in r.stderr and 'nonexistent.kns' in r.stderr
+
+    def samples(p):
+        with wave.open(str(p)) as w:
+            return np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+    k = koala_amd.create('key', model_path=gate_model)
+    want = enhance_single(k, read_wav(GOLDEN + '/test.wav', 16000))
+    k.delete()
+    assert np.array_equal(samples(out1), want) and np.array_equal(samples(out2), want)
