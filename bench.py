@@ -4,20 +4,30 @@ bench.py -- throughput of the pv_koala_process hot path on MI355X (BASELINE.json
 batch 4096, configs[2]: bf16 mask GEMMs on MFMA + fp32 FFT).
 
 One "step" = one pv_koala_batch_process_chunk call: 4096 streams x 64 frames (1.024 s of audio per stream) per GPU,
-int16 PCM already resident in HBM, enhanced PCM left in HBM.  N > 1: one process per GPU (torchrun), each rank owns
-its own 4096 streams (weak scaling, no data-path collective); the only collective is the final RCCL all-reduce of
-{frames, max elapsed}.
+int16 PCM already resident in HBM, enhanced PCM left in HBM.
+
+Multi-GPU: one process per GPU, each rank owns its own 4096 streams (weak scaling, no data-path
+collective); the only collective is the final RCCL all-reduce of {frames, max elapsed}.  `python bench.py --gpus N`
+launches the N ranks ITSELF (one child per GPU, LOCAL_RANK = GPU index, rendezvous on 127.0.0.1); started by
+torchrun / torch.distributed.run it uses the ranks it was given.  `n_gpus` in the output is the world size RCCL saw,
+and a WORLD_SIZE that differs from --gpus is an error (exit status 2), never a silent single-GPU run.
 
 Prints ONE JSON line (rank 0).  Besides the driver's fields it carries
   roofline      dominant kernel (by device time) priced against its bound: algorithmic work per launch / mean launch
                 duration measured with HIP events on the engine's stream in a second, identical pass
-  stages        the same for every kernel class
-  cpu_baseline  the CPU oracle (a "port": plain-C restatement, OpenMP over streams) on a bounded sample of the same
-                workload on this box's host cores -- a reported baseline, not the target
+  stages        the same for every kernel class (HBM-bound stages also against the bytes they were measured to move)
+  cpu_baseline  the CPU oracle (a "port": plain-C restatement, OpenMP over stream blocks) on a bounded sample of the
+                same workload on this box's host cores -- a reported baseline, not the target
+  extra         the other BASELINE operating points, timed in the same run (N = 1 only): configs[1] (256 streams,
+                fp32), configs[4] (one stream, one frame per pv_koala_process call: p50/p99), one frame per call at
+                4096 streams, the host-pointer (PCIe-inclusive) path, and the |GPU - oracle| histogram of the timed
+                batch's first call
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,7 +48,7 @@ MAC_GRU = 8 * H * G3                                      # 8 recurrent GEMMs (W
 MAC_HEAD = 257 * H + H * sum(HEADS)                       # front-end + 4 heads
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
@@ -50,10 +60,141 @@ def main():
     ap.add_argument('--frames', type=int, default=64, help='frames per stream per call (64 = 1.02 s of audio)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the other operating points (profiling runs)')
     ap.add_argument('--library', default=None, help='alternative libpv_koala.so (developer A/B runs)')
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL over xGMI) for real runs; gloo only to test the '
                     'multi-rank code path on a single-GPU box together with KOALA_BENCH_SHARE_GPU=1')
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start one child per GPU and relay rank 0's line."""
+    import koala_amd
+    koala_amd.build_native()  # once, before the ranks exist
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    deadline = time.time() + 3600
+    alive = list(procs)
+    while alive and time.time() < deadline:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:  # one rank failed: the others would wait in a collective forever
+                    q.terminate()
+        time.sleep(0.05)
+    for p in alive:
+        p.kill()
+        rc = rc or 124
+    return rc
+
+
+def time_steps(fn, sync, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    sync()
+    return time.perf_counter() - t0
+
+
+def machine_state():
+    """What resources/scripts/machine-state.sh of the reference logs around its perf runs: load and memory."""
+    st = {}
+    try:
+        st['loadavg_1m'] = float(open('/proc/loadavg').read().split()[0])
+        mem = dict((l.split(':')[0], int(l.split()[1])) for l in open('/proc/meminfo') if ':' in l)
+        st['mem_used_pct'] = round(100.0 * (1.0 - mem['MemAvailable'] / float(mem['MemTotal'])), 1)
+    except Exception:
+        pass
+    return st
+
+
+def extra_points(args, torch, np, koala_amd, model, kb, x, dx, dy, base, local_rank):
+    """The other BASELINE operating points, on the same box in the same run (rank 0 of a single-GPU run)."""
+    from koala_amd.workload import synth_streams
+    B, T = args.streams, args.frames
+    out = {}
+    sync = torch.cuda.synchronize
+    dev = 'gpu:%d' % local_rank
+
+    # -- one frame per call at the bench batch (the reference's calling convention, batched)
+    d1 = dx[:, :256].contiguous()
+    o1 = torch.empty_like(d1)
+    dt = time_steps(lambda: kb.process_device(1, d1.data_ptr(), o1.data_ptr()), sync, 300, 30)
+    out['streaming_T1'] = {'workload': '%d streams x 1 frame per call, %s, device-resident' % (B, args.precision),
+                           'frames_per_s': round(B * 300 / dt, 1), 'ms_per_call': round(dt / 300 * 1e3, 4)}
+
+    # -- host-pointer (PCIe-inclusive) path at the bench size: pageable numpy arrays, then page-locked ones
+    y = np.empty_like(x)
+    dt = time_steps(lambda: kb.process_into(x, y), lambda: None, 4, 1)
+    out['host_pageable'] = {'workload': '%d x %d frames per call, caller buffers in pageable host memory' % (B, T),
+                            'frames_per_s': round(B * T * 4 / dt, 1)}
+    px, py = kb.alloc_host(T), kb.alloc_host(T)
+    px[:] = x
+    dt = time_steps(lambda: kb.process_into(px, py), lambda: None, 4, 1)
+    out['host_pinned'] = {'workload': '%d x %d frames per call, caller buffers page-locked (pv_koala_batch_host_alloc)' % (B, T),
+                          'frames_per_s': round(B * T * 4 / dt, 1)}
+
+    # -- BASELINE configs[1]: 256 streams, fp32 mask network
+    for T1 in (32, 1):
+        k1 = koala_amd.create_batch('bench', 256, T1, 'fp32', model_path=model, device=dev, library_path=args.library)
+        k1.set_stream(torch.cuda.current_stream().cuda_stream)
+        a = torch.from_numpy(np.ascontiguousarray(np.tile(base, (4, 1))[:256, :T1 * 256])).cuda()
+        b = torch.empty_like(a)
+        n = 60 if T1 > 1 else 300
+        dt = time_steps(lambda: k1.process_device(T1, a.data_ptr(), b.data_ptr()), sync, n, 10)
+        out['config1_fp32_b256_T%d' % T1] = {
+            'workload': 'BASELINE configs[1]: 256 streams x %d frame(s) per call, fp32 mask net, device-resident' % T1,
+            'frames_per_s': round(256 * T1 * n / dt, 1), 'ms_per_call': round(dt / n * 1e3, 4)}
+        k1.delete()
+
+    # -- BASELINE configs[4]: one stream, one frame per pv_koala_process call (hipGraph replay, host buffers)
+    frame = np.ascontiguousarray(base[0, :256])
+    for prec in ('fp32', 'bf16'):
+        os.environ['KOALA_AMD_PRECISION'] = prec
+        k = koala_amd.create('bench', model_path=model, device=dev, library_path=args.library)
+        for _ in range(200):
+            k.process(frame)
+        lat = np.empty(3000)
+        for i in range(3000):
+            t0 = time.perf_counter()
+            k.process(frame)
+            lat[i] = time.perf_counter() - t0
+        k.delete()
+        out['config4_b1_%s' % prec] = {
+            'workload': 'BASELINE configs[4]: 1 stream, 1 frame per pv_koala_process call through the Python binding '
+                        '(numpy frame in, list out), %s' % prec,
+            'p50_us': round(float(np.percentile(lat, 50)) * 1e6, 1), 'p99_us': round(float(np.percentile(lat, 99)) * 1e6, 1),
+            'frames_per_s': round(1.0 / float(np.mean(lat)), 1),
+            'real_time_factor': round(float(np.mean(lat)) / 0.016, 5)}
+    os.environ.pop('KOALA_AMD_PRECISION', None)
+    return out
+
+
+def main():
+    args = parse_args()
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    world_env = int(env_world or '1')
+    if world_env != args.gpus:
+        print('bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a number for a different job than the one asked for'
+              % (args.gpus, world_env), file=sys.stderr)
+        sys.exit(2)
 
     import numpy as np
     import torch
@@ -65,10 +206,15 @@ def main():
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if os.environ.get('KOALA_BENCH_SHARE_GPU'):
+    share_gpu = bool(os.environ.get('KOALA_BENCH_SHARE_GPU'))
+    if share_gpu:
         local_rank = 0  # test mode: every rank drives GPU 0
-    if world > 1:
+    if not share_gpu and torch.cuda.device_count() < (local_rank + 1):
+        print('bench.py: rank %d needs GPU %d but only %d visible' % (rank, local_rank, torch.cuda.device_count()),
+              file=sys.stderr)
+        sys.exit(2)
+    world = 1
+    if world_env > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -77,19 +223,19 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group(args.dist_backend)
+        world = dist.get_world_size()  # what the communicator was actually built with
     else:
         torch.cuda.set_device(local_rank)
-    if args.gpus != world and rank == 0 and world > 1:
-        print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
 
     koala_amd.build_native()
     model = params.ensure_params(os.path.join(ROOT, 'build', 'random_1234.kns'), 'random', 1234)
     B, T = args.streams, args.frames
     first, _ = shard_range(B * world, rank, world)
 
-    # synthetic input: 64 distinct seeded streams tiled over the batch (generation cost, not data-path cost)
-    base = synth_streams(64, T, seed=1234, first_stream=(first % 4096))
-    x = np.tile(base, ((B + 63) // 64, 1))[:B]
+    # synthetic input: `distinct` seeded streams tiled over the batch (generation cost, not data-path cost)
+    distinct = min(B, 1024 if (rank == 0 and world == 1 and not args.no_cpu_baseline) else 64)
+    base = synth_streams(distinct, T, seed=1234, first_stream=(first % 4096))
+    x = np.ascontiguousarray(np.tile(base, ((B + distinct - 1) // distinct, 1))[:B])
     dx = torch.from_numpy(x).cuda()
     dy = torch.empty_like(dx)
 
@@ -105,6 +251,11 @@ def main():
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
+
+    # the first call after creation is also the parity sample (checked against the oracle further down)
+    step()
+    torch.cuda.synchronize()
+    first_call = dy[:distinct].cpu().numpy() if (rank == 0 and world == 1) else None
 
     t_prime = time.perf_counter()
     while time.perf_counter() - t_prime < args.prime_seconds:  # clock ramp, untimed (see --prime-seconds)
@@ -156,56 +307,71 @@ def main():
                         'launches_per_step': round(actual, 2) if actual != int(actual) else int(actual),
                         'share_of_device_time': round(ms * actual / dev_ms, 4) if dev_ms else None}
     dominant = max(stages, key=lambda k: stages[k]['avg_launch_ms'] * stages[k]['launches_per_step'])
-    roofline = dict(stages[dominant])
-    roofline['kernel'] = dominant
     # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command (tools/pmc_run.sh ->
-    # profiles/*_pmc.json; FETCH_SIZE doubled per the gfx950 correction); they cannot be collected inside a timed run
-    roofline['traffic'] = None
+    # profiles/*_pmc.json; FETCH_SIZE doubled per the gfx950 correction); they cannot be collected inside a timed run.
+    # `traffic_commit` is the source revision the counters were collected on: compare it with HEAD to see staleness.
+    traffic_meta = {}
     try:
         import glob
         pmc_files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json')))
         pmc = json.load(open(pmc_files[-1])) if pmc_files else {}
         wl = pmc.pop('_workload', None)
+        commit = pmc.pop('_commit', None)
         if wl == {'streams_per_gpu': B, 'frames_per_call': T, 'dtype': args.precision}:
-            for entry in pmc.values():
-                if entry.get('class') == dominant and 'hbm_bytes' in entry:
-                    roofline['traffic'] = entry['hbm_bytes']
-                    roofline['traffic_source'] = os.path.basename(pmc_files[-1])
+            traffic_meta = {'traffic_source': os.path.basename(pmc_files[-1]), 'traffic_commit': commit,
+                            'traffic_measured_in_this_run': False}
             for name in stages:
                 for entry in pmc.values():
-                    if entry.get('class') == name and 'hbm_bytes' in entry:
+                    if isinstance(entry, dict) and entry.get('class') == name and 'hbm_bytes' in entry:
                         stages[name]['traffic'] = entry['hbm_bytes']
+                        if stages[name]['bound'] == 'hbm':  # against the bytes the kernel was measured to move
+                            gbs = entry['hbm_bytes'] / (stages[name]['avg_launch_ms'] * 1e-3) / 1e9
+                            stages[name]['traffic_GBps'] = round(gbs, 1)
+                            stages[name]['frac_of_peak_by_traffic'] = round(gbs / HBM_PEAK_GBS, 4)
     except Exception:
         pass
+    roofline = dict(stages[dominant])
+    roofline['kernel'] = dominant
+    roofline.setdefault('traffic', None)
+    roofline.update(traffic_meta)
 
-    # ---- parity spot check inside the bench: the timed engine vs the CPU oracle on a few streams
+    # ---- CPU baseline + parity check of what was timed (rank 0 of a single-GPU run only)
     cpu = None
+    parity = None
+    extra = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
         ncores = os.cpu_count() or 1
+        before = machine_state()
         # calibrate, then size the sample for ~10-20 s of CPU work
         o = oracle.Oracle(model, 1024, oracle.PREC_FP32)
-        xs = np.ascontiguousarray(np.tile(base, (16, 1))[:, :8 * 256])
+        xs = np.ascontiguousarray(x[:1024, :8 * 256]) if B >= 1024 else np.ascontiguousarray(np.tile(base, (16, 1))[:1024, :8 * 256])
         c0 = time.perf_counter()
         o.process(xs)
         rate = 1024 * 8 / (time.perf_counter() - c0)
         ns = int(min(16384, max(64, (rate * 15) // (T * 64) * 64)))
         o = oracle.Oracle(model, ns, oracle.PREC_FP32)
-        xs = np.ascontiguousarray(np.tile(base, ((ns + 63) // 64, 1))[:ns])
+        xs = np.ascontiguousarray(np.tile(base, ((ns + distinct - 1) // distinct, 1))[:ns])
         c0 = time.perf_counter()
-        ref = o.process(xs)
+        o.process(xs)
         dt = time.perf_counter() - c0
         cpu = {'value': round(ns * T / dt, 1), 'unit': 'frames/s', 'cores': ncores, 'kind': 'port',
-               'sample': '%d streams x %d frames of the same synthetic workload, oracle/kns_oracle.c fp32, OpenMP '
-                         'over stream blocks, %.1f s' % (ns, T, dt)}
-        # and use it as a checker of what was just timed (first call after a reset)
-        kb.reset()
-        step()
-        torch.cuda.synchronize()
-        got = dy[:64].cpu().numpy().astype(np.int64)
-        want = oracle.Oracle(model, 64, oracle.PREC_BF16 if args.precision == 'bf16' else oracle.PREC_FP32).process(
-            np.ascontiguousarray(x[:64])).astype(np.int64)
-        cpu['gpu_vs_oracle_max_lsb'] = int(np.abs(got - want).max())
+               'sample': '%d streams x %d frames of the same synthetic workload, oracle/kns_oracle.c fp32 (register-blocked '
+                         'k-ascending fmaf GEMMs, OpenMP over stream blocks of %d), %.1f s'
+                         % (ns, T, oracle.block_size(), dt),
+               'machine_state_before': before, 'machine_state_after': machine_state()}
+        # parity of the timed engine's first call against the oracle run with the same rounding points, over every
+        # distinct stream of the batch
+        want = oracle.Oracle(model, distinct, oracle.PREC_BF16 if args.precision == 'bf16' else oracle.PREC_FP32).process(
+            np.ascontiguousarray(x[:distinct])).astype(np.int64)
+        d = np.abs(first_call.astype(np.int64) - want)
+        hist = np.bincount(np.minimum(d.ravel(), 8), minlength=9)
+        parity = {'streams': int(distinct), 'frames': T, 'oracle': 'kns_oracle.c, %s rounding points' % args.precision,
+                  'max_lsb': int(d.max()), 'abs_diff_histogram_0_to_8plus': hist.tolist(),
+                  'within_1_lsb': round(float((d <= 1).mean()), 6)}
+        cpu['gpu_vs_oracle_max_lsb'] = parity['max_lsb']
+    if rank == 0 and world == 1 and not args.no_extra:
+        extra = extra_points(args, torch, np, koala_amd, model, kb, x, dx, dy, base, local_rank)
 
     kb.delete()
     if world > 1:
@@ -238,8 +404,11 @@ def main():
         'roofline': roofline,
         'stages': stages,
         'cpu_baseline': cpu,
+        'parity': parity,
+        'extra': extra,
     }
     print(json.dumps(line))
+    sys.stdout.flush()
 
 
 if __name__ == '__main__':

@@ -25,8 +25,22 @@ def build_native(force: bool = False) -> str:
     inc = os.path.join(_PKG, '..', 'include')
     if os.path.isdir(inc):
         deps += [os.path.join(inc, n) for n in os.listdir(inc)]
-    if force or not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
-        subprocess.check_call(['make', '-C', _PKG, '-s', 'lib/libpv_koala.so'])
+
+    def stale():
+        return not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps)
+
+    if force or stale():
+        # several ranks (torchrun) may get here at once: one builds, the others wait on the lock and find the result;
+        # the Makefile links to a temporary name and renames, so a library is never observed half-written
+        import fcntl
+        os.makedirs(os.path.dirname(lib), exist_ok=True)
+        with open(os.path.join(os.path.dirname(lib), '.build.lock'), 'w') as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if force or stale():
+                    subprocess.check_call(['make', '-C', _PKG, '-s'] + (['-B'] if force else []) + ['lib/libpv_koala.so'])
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     model = default_model_path()
     if not os.path.exists(model):
         from . import params

@@ -35,7 +35,15 @@ LoadResult load_params(const char *path, Params *p, std::string *err) {
     }
     char magic[8];
     uint32_t hdr[14];
-    bool ok = fread(magic, 1, 8, f) == 8 && fread(hdr, 4, 14, f) == 14 && memcmp(magic, "KNS1\0\0\0\0", 8) == 0;
+    bool ok = fread(magic, 1, 8, f) == 8;
+    if (ok && memcmp(magic, "koala", 5) == 0) {
+        // the reference's own parameter file (lib/common/koala_params.pv, magic "koala3.0.0"): closed fixed-point format
+        fclose(f);
+        *err = std::string("`") + path + "` is a reference Koala `.pv` model: its fixed-point format is not documented and "
+               "is not supported; pass a KNS1 (.kns) parameter file.";
+        return kLoadFormat;
+    }
+    ok = ok && fread(hdr, 4, 14, f) == 14 && memcmp(magic, "KNS1\0\0\0\0", 8) == 0;
     ok = ok && hdr[0] == 1 && hdr[1] == kNfft && hdr[2] == kFrame && hdr[3] == kBins && hdr[4] == kHidden &&
          hdr[5] == kStages && hdr[9] == kBins && hdr[10] == kFrame;
     if (!ok) {
@@ -230,6 +238,8 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     }
     stream_ = own_stream_;
     use_graph_ = getenv("KOALA_AMD_NO_GRAPH") == nullptr;
+    no_small_ = getenv("KOALA_AMD_NO_SMALL") != nullptr;          // developer switches, read once (not per frame)
+    no_zero_copy_ = getenv("KOALA_AMD_NO_ZERO_COPY") != nullptr;
     // host-pointer calls are cut into sub-chunks of host_chunk_ frames (two staging slots = the Tmax-sized buffers)
     host_chunk_ = Tmax_ / 2 < 1 ? 1 : (Tmax_ / 2 > 16 ? 16 : Tmax_ / 2);
     host_pipeline_min_bytes_ = (size_t) 4 << 20;  // below this a call is launch-bound: sub-chunks would only add launches
@@ -447,8 +457,13 @@ bool Engine::reset(const uint8_t *host_mask, std::string *err) {
     if (host_mask) {
         std::vector<uint8_t> m((size_t) Bpad_, 0);
         memcpy(m.data(), host_mask, (size_t) B_);
-        (void) hipMemcpyAsync(d_rmask_, m.data(), (size_t) Bpad_, hipMemcpyHostToDevice, stream_);
-        (void) hipStreamSynchronize(stream_);  // `m` goes out of scope
+        hipError_t ce = hipMemcpyAsync(d_rmask_, m.data(), (size_t) Bpad_, hipMemcpyHostToDevice, stream_);
+        if (ce == hipSuccess) ce = hipStreamSynchronize(stream_);  // `m` goes out of scope
+        if (ce != hipSuccess) {  // a stale mask would reset the wrong streams: report, do not launch
+            (void) hipGetLastError();
+            *err = std::string("HIP error: ") + hipGetErrorString(ce);
+            return false;
+        }
         r.mask = d_rmask_;
     }
     launch_reset(r, stream_);
@@ -526,7 +541,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     };
 
     // one frame of a few m-tiles: latency matters, not throughput -- whole GRU layers as single wide launches
-    const bool small = T == 1 && mtb <= 16 && getenv("KOALA_AMD_NO_SMALL") == nullptr;
+    const bool small = T == 1 && mtb <= 16 && !no_small_;
     // Fewer than 256 m-tiles: the chunked recurrent kernels would occupy mtb workgroups, so the layers run frame
     // by frame through the low-latency kernel instead (17 x mtb workgroups of three waves per frame, input GEMM included):
     // in fp32 at 256 streams x 32 frames 8 x 32 launches of ~13 us beat 8 x (0.1 + 0.75) ms (2.8 vs 1.2 M frames/s; 5.5 vs
@@ -535,7 +550,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     static const int steps_mt = getenv("KOALA_AMD_STEPS_MT") ? atoi(getenv("KOALA_AMD_STEPS_MT")) : 192;  // tuning switch
     // (fp32 only: the bf16 recurrent kernel keeps its weights on chip and is faster than 8 us per frame and layer even
     // with 16 workgroups -- 11.3 vs 5.2 M frames/s at 256 streams; the fp32 one streams them: 1.2 vs 2.8 M)
-    const bool small_steps = T > 1 && mtb <= steps_mt && prec_ != kBf16 && getenv("KOALA_AMD_NO_SMALL") == nullptr;
+    const bool small_steps = T > 1 && mtb <= steps_mt && prec_ != kBf16 && !no_small_;
     auto gru_small = [&](const void *a0, int nb0, const void *a1, const void *wih, const float *bih, const void *whh,
                          const float *bhh, int layer, void *hseq, int t = 0) {
         GruSmallArgs g;
@@ -689,7 +704,13 @@ bool Engine::process_host_pipelined(int T, const int16_t *pcm, int16_t *out, boo
         // ---- kernels (d_out_ slot s was last drained by the D2H of chunk c - 2)
         check(hipStreamWaitEvent(stream_, ev_in_[s], 0));
         if (c >= 2) check(hipStreamWaitEvent(stream_, ev_out_[s], 0));
-        if (ok && !run_device(tc, d_in_ + s * slot, d_out_ + s * slot, err)) return false;
+        if (ok && !run_device(tc, d_in_ + s * slot, d_out_ + s * slot, err)) {
+            // copies of earlier sub-chunks may still be writing into the caller's buffers: let them finish first
+            (void) hipStreamSynchronize(copy_in_);
+            (void) hipStreamSynchronize(copy_out_);
+            (void) hipStreamSynchronize(stream_);
+            return false;
+        }
         check(hipEventRecord(ev_done_[s], stream_));
         // ---- copy-out
         check(hipStreamWaitEvent(copy_out_, ev_done_[s], 0));
@@ -718,10 +739,11 @@ bool Engine::process_host_pipelined(int T, const int16_t *pcm, int16_t *out, boo
     return ok;
 }
 
-bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err) {
+bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err, bool host_pointers) {
     (void) hipSetDevice(device_);
     const size_t bytes = (size_t) B_ * T * kFrame * 2;
-    const PointerKind kin = pointer_kind(pcm), kout = pointer_kind(out);
+    // (the single-stream ABI takes host buffers by contract: no driver query per frame on the latency path)
+    const PointerKind kin = host_pointers ? kPtrPageable : pointer_kind(pcm), kout = host_pointers ? kPtrPageable : pointer_kind(out);
     if ((kin == kPtrDevice) != (kout == kPtrDevice)) {
         *err = "`pcm` and `enhanced` must both be host or both be device memory.";
         return false;
@@ -742,23 +764,34 @@ bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err) 
             // (relaxed mode and one capture at a time in the process: other threads -- other handles being created, the
             // host application -- may touch the legacy stream meanwhile, which would invalidate a stricter capture)
             std::lock_guard<std::mutex> capture_lock(g_capture_mutex);
-            if (hipStreamBeginCapture(stream_, hipStreamCaptureModeRelaxed) != hipSuccess) goto fail;
-            // small batches: the analysis kernel reads the frame from, and the synthesis kernel writes it to, the pinned
-            // host staging buffers directly (device-visible memory): two copy nodes of ~4 us each less per frame
-            const bool zero_copy = bytes <= 64 * 1024 && getenv("KOALA_AMD_NO_ZERO_COPY") == nullptr;
-            bool ok = zero_copy || hipMemcpyAsync(d_in_, h_in_, bytes, hipMemcpyHostToDevice, stream_) == hipSuccess;
-            ok = ok && run_device(1, zero_copy ? h_in_ : d_in_, zero_copy ? h_out_ : d_out_, err);
-            ok = ok && (zero_copy || hipMemcpyAsync(h_out_, d_out_, bytes, hipMemcpyDeviceToHost, stream_) == hipSuccess);
-            if (hipStreamEndCapture(stream_, &graph) != hipSuccess || !ok) goto fail;
-            if (hipGraphInstantiate(&frame_graph_[parity], graph, nullptr, nullptr, 0) != hipSuccess) goto fail;
-            (void) hipGraphDestroy(graph);
+            bool ok = hipStreamBeginCapture(stream_, hipStreamCaptureModeRelaxed) == hipSuccess;
+            if (ok) {
+                // small batches: the analysis kernel reads the frame from, and the synthesis kernel writes it to, the
+                // pinned host staging buffers directly (device-visible memory): two copy nodes of ~4 us each less per frame
+                const bool zero_copy = bytes <= 64 * 1024 && !no_zero_copy_;
+                ok = zero_copy || hipMemcpyAsync(d_in_, h_in_, bytes, hipMemcpyHostToDevice, stream_) == hipSuccess;
+                ok = ok && run_device(1, zero_copy ? h_in_ : d_in_, zero_copy ? h_out_ : d_out_, err);
+                ok = ok && (zero_copy || hipMemcpyAsync(h_out_, d_out_, bytes, hipMemcpyDeviceToHost, stream_) == hipSuccess);
+                ok = (hipStreamEndCapture(stream_, &graph) == hipSuccess) && ok;
+                ok = ok && hipGraphInstantiate(&frame_graph_[parity], graph, nullptr, nullptr, 0) == hipSuccess;
+                if (graph) (void) hipGraphDestroy(graph);
+            }
             hs_cur_ = hs;  // the capture only recorded the launches; run_device's bookkeeping is replayed below
+            if (!ok) {
+                // a failed capture must not leave the handle half-switched: nothing was executed, the ping-pong index is
+                // back where it was, and this and every later frame take the plain copy / launch / copy path below
+                (void) hipGetLastError();
+                frame_graph_[parity] = nullptr;
+                use_graph_ = false;
+            }
         }
-        if (hipGraphLaunch(frame_graph_[parity], stream_) != hipSuccess) goto fail;
-        hs_cur_ = hs ^ 1;
-        if (hipStreamSynchronize(stream_) != hipSuccess) goto fail;
-        memcpy(out, h_out_, bytes);
-        return true;
+        if (use_graph_) {
+            if (hipGraphLaunch(frame_graph_[parity], stream_) != hipSuccess) goto fail;
+            hs_cur_ = hs ^ 1;
+            if (hipStreamSynchronize(stream_) != hipSuccess) goto fail;
+            memcpy(out, h_out_, bytes);
+            return true;
+        }
     }
     if (hipMemcpyAsync(d_in_, h_in_, bytes, hipMemcpyHostToDevice, stream_) != hipSuccess) goto fail;
     if (!run_device(T, d_in_, d_out_, err)) return false;

@@ -41,7 +41,7 @@ public:
     int device() const { return device_; }
 
     // pcm/out: [B][T*256]; host or device pointers (both of the same kind).  Host: synchronous.  Device: enqueued.
-    bool process(int T, const int16_t *pcm, int16_t *out, std::string *err);
+    bool process(int T, const int16_t *pcm, int16_t *out, std::string *err, bool host_pointers = false);
     bool reset(const uint8_t *host_mask, std::string *err);
     void set_stream(hipStream_t s) { stream_ = s ? s : own_stream_; }
     bool synchronize(std::string *err);
@@ -99,7 +99,7 @@ private:
 
     // hipGraph of one host-pointer frame (copy-in, 23 kernels, copy-out); built on first use
     hipGraphExec_t frame_graph_[8] = {};  // one per combination of the hidden-state / history / tail ping-pong indices
-    bool use_graph_ = true;
+    bool use_graph_ = true, no_small_ = false, no_zero_copy_ = false;
 
     // profiling
     bool profiling_ = false;

@@ -58,7 +58,12 @@ struct DeviceSpec {
 };
 
 // grammar of the reference's `device` argument (include/pv_koala.h:42-46): best | cpu | cpu:N | gpu | gpu:N
-bool parse_device(const char *s, DeviceSpec *out) {
+bool parse_device(const char *text, DeviceSpec *out) {
+    // an entry of pv_koala_list_hardware_devices ("gpu:0 - <name>") is accepted as it was printed
+    std::string head(text);
+    const size_t dash = head.find(" - ");
+    if (dash != std::string::npos && dash > 0) head.resize(dash);
+    const char *s = head.c_str();
     auto number = [](const char *p, int *v) {
         if (!*p) return false;
         long n = 0;
@@ -266,7 +271,7 @@ PV_API pv_status_t pv_koala_process(pv_koala_t *object, const int16_t *pcm, int1
         return PV_STATUS_INVALID_ARGUMENT;
     }
     std::string err;
-    if (!object->engine->process(1, pcm, enhanced_pcm, &err)) {
+    if (!object->engine->process(1, pcm, enhanced_pcm, &err, /*host_pointers=*/true)) {
         push_error(0x337, "%s", err.c_str());
         push_error(0x12C, "Picovoice Error.");
         return PV_STATUS_RUNTIME_ERROR;

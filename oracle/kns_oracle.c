@@ -14,6 +14,7 @@
  */
 #include "kns_oracle.h"
 
+#include <immintrin.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -314,9 +315,11 @@ struct kns_oracle {
 };
 
 /* acc[s][n] = sum_k x[s][k] * w[k][n] as a k-ascending fmaf chain starting from 0, then + bias[n].
- * `q` optionally rounds the activation operand (bf16 mode).  x rows have stride ldx. */
-static void gemm_block(int nb, const float *x, int ldx, int K, const float *w, int N, const float *bias, float *acc,
-                       int lda, int round_x) {
+ * `round_x` rounds the activation operand (bf16 mode).  x rows have stride ldx.
+ * This is the plain statement of the arithmetic; gemm_block() below computes the same chains, bit for bit, with the
+ * loops blocked for registers and caches (selected unless KNS_ORACLE_SIMPLE_GEMM is set in the environment). */
+static void gemm_block_simple(int nb, const float *x, int ldx, int K, const float *w, int N, const float *bias, float *acc,
+                              int lda, int round_x) {
     for (int s = 0; s < nb; ++s) memset(acc + (size_t) s * lda, 0, sizeof(float) * (size_t) N);
     for (int k = 0; k < K; ++k) {
         const float *wr = w + (size_t) k * N;
@@ -331,6 +334,74 @@ static void gemm_block(int nb, const float *x, int ldx, int K, const float *w, i
         float *a = acc + (size_t) s * lda;
         for (int n = 0; n < N; ++n) a[n] = a[n] + bias[n];
     }
+}
+
+/* Register-blocked form: R (up to 6) stream rows x 16 columns of accumulators live in 2R AVX registers while k runs over
+ * the whole chain (one IEEE fma per lane and k step = fmaf), and a 16-column weight panel (K x 64 B) is reused from cache
+ * by every row group of the block.  Each (s, n) is still its own k-ascending chain from 0 with the bias added last, so
+ * the result is identical to gemm_block_simple; only the order in which independent chains are advanced differs. */
+#define KNS_PANEL_KERNEL(R)                                                                                             \
+    static void panel16_r##R(const float *x, int ldx, int K, const float *w, int N, const float *bias, float *acc,     \
+                             int lda) {                                                                                 \
+        __m256 a[R][2];                                                                                                 \
+        for (int r = 0; r < R; ++r) a[r][0] = a[r][1] = _mm256_setzero_ps();                                            \
+        for (int k = 0; k < K; ++k) {                                                                                   \
+            const float *wr = w + (size_t) k * N;                                                                       \
+            const __m256 w0 = _mm256_loadu_ps(wr), w1 = _mm256_loadu_ps(wr + 8);                                        \
+            for (int r = 0; r < R; ++r) {                                                                               \
+                const __m256 xb = _mm256_broadcast_ss(x + (size_t) r * ldx + k);                                        \
+                a[r][0] = _mm256_fmadd_ps(xb, w0, a[r][0]);                                                             \
+                a[r][1] = _mm256_fmadd_ps(xb, w1, a[r][1]);                                                             \
+            }                                                                                                           \
+        }                                                                                                               \
+        for (int r = 0; r < R; ++r) {                                                                                   \
+            _mm256_storeu_ps(acc + (size_t) r * lda, _mm256_add_ps(a[r][0], _mm256_loadu_ps(bias)));                    \
+            _mm256_storeu_ps(acc + (size_t) r * lda + 8, _mm256_add_ps(a[r][1], _mm256_loadu_ps(bias + 8)));            \
+        }                                                                                                               \
+    }
+KNS_PANEL_KERNEL(1)
+KNS_PANEL_KERNEL(2)
+KNS_PANEL_KERNEL(3)
+KNS_PANEL_KERNEL(4)
+KNS_PANEL_KERNEL(5)
+KNS_PANEL_KERNEL(6)
+
+static int g_simple_gemm = -1;
+
+static void gemm_block(int nb, const float *x, int ldx, int K, const float *w, int N, const float *bias, float *acc,
+                       int lda, int round_x) {
+    if (g_simple_gemm < 0) g_simple_gemm = getenv("KNS_ORACLE_SIMPLE_GEMM") != NULL;
+    if (g_simple_gemm) {
+        gemm_block_simple(nb, x, ldx, K, w, N, bias, acc, lda, round_x);
+        return;
+    }
+    float *xr = NULL;
+    if (round_x) { /* round the activation operand once, not once per column panel */
+        xr = (float *) malloc(sizeof(float) * (size_t) nb * (size_t) K);
+        for (int s = 0; s < nb; ++s)
+            for (int k = 0; k < K; ++k) xr[(size_t) s * K + k] = kns_round_bf16(x[(size_t) s * ldx + k]);
+        x = xr;
+        ldx = K;
+    }
+    typedef void (*panel_fn)(const float *, int, int, const float *, int, const float *, float *, int);
+    static const panel_fn kernels[7] = {NULL, panel16_r1, panel16_r2, panel16_r3, panel16_r4, panel16_r5, panel16_r6};
+    const int n32 = N & ~15;
+    for (int n0 = 0; n0 < n32; n0 += 16)
+        for (int s = 0; s < nb; s += 6) {
+            const int r = nb - s < 6 ? nb - s : 6;
+            kernels[r](x + (size_t) s * ldx, ldx, K, w + n0, N, bias + n0, acc + (size_t) s * lda + n0, lda);
+        }
+    /* remaining columns (N mod 16; the narrowest heads entirely): the same chains, column by column */
+    for (int s = 0; s < nb && n32 < N; ++s) {
+        const float *xs = x + (size_t) s * ldx;
+        float *a = acc + (size_t) s * lda;
+        for (int n = n32; n < N; ++n) {
+            float v = 0.0f;
+            for (int k = 0; k < K; ++k) v = fmaf(xs[k], w[(size_t) k * N + n], v);
+            a[n] = v + bias[n];
+        }
+    }
+    free(xr);
 }
 
 /* one GRU layer step for a block of streams:  x [nb][K] -> h (in/out) [nb] pointers */
@@ -439,22 +510,32 @@ void kns_oracle_reset(kns_oracle_t *o, const uint8_t *mask) {
         if (!mask || mask[s]) memset(&o->st[s], 0, sizeof(kns_stream_t));
 }
 
+static int g_last_block = KNS_MAX_BLOCK;
+int kns_oracle_last_block(void) { return g_last_block; }
+
 int kns_oracle_process(kns_oracle_t *o, int num_frames, const int16_t *pcm, int16_t *enhanced, int num_threads) {
     if (!o || !pcm || !enhanced || num_frames <= 0) return -1;
     const int B = o->num_streams;
-    const int nblocks = (B + KNS_MAX_BLOCK - 1) / KNS_MAX_BLOCK;
     const size_t row = (size_t) num_frames * KNS_FRAME;
 #ifdef _OPENMP
     if (num_threads <= 0) num_threads = omp_get_max_threads();
 #else
-    (void) num_threads;
+    num_threads = 1;
 #endif
+    /* streams per block: as many as share one pass over the weights (up to KNS_MAX_BLOCK) while every thread still gets
+     * a block; a stream's result does not depend on the blocking */
+    int blk = (B + num_threads - 1) / num_threads;
+    blk = (blk + 3) & ~3;
+    if (blk > KNS_MAX_BLOCK) blk = KNS_MAX_BLOCK;
+    if (blk < 4) blk = 4;
+    g_last_block = blk;
+    const int nblocks = (B + blk - 1) / blk;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads)
     for (int b = 0; b < nblocks; ++b) {
         kns_scratch_t *w = (kns_scratch_t *) malloc(sizeof(kns_scratch_t));
         memset(w->y, 0, sizeof(w->y));
-        const int s0 = b * KNS_MAX_BLOCK;
-        const int nb = (B - s0) < KNS_MAX_BLOCK ? (B - s0) : KNS_MAX_BLOCK;
+        const int s0 = b * blk;
+        const int nb = (B - s0) < blk ? (B - s0) : blk;
         kns_stream_t *st[KNS_MAX_BLOCK];
         const int16_t *in[KNS_MAX_BLOCK];
         int16_t *out[KNS_MAX_BLOCK];

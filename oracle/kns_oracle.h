@@ -33,7 +33,7 @@ extern "C" {
 #define KNS_H 271
 #define KNS_STAGES 4
 #define KNS_G3 (3 * KNS_H)
-#define KNS_MAX_BLOCK 16
+#define KNS_MAX_BLOCK 64 /* streams that share one pass over the weights in kns_oracle_process */
 
 /* precision modes: which rounding points of the GPU pipeline are emulated */
 #define KNS_PREC_FP32 0 /* no rounding anywhere; GEMMs are k-ordered fmaf chains                    */
@@ -64,6 +64,9 @@ int kns_oracle_delay_sample(void);
 
 /* pcm, enhanced: [num_streams][num_frames*256] row-major int16.  num_threads<=0 -> all cores. */
 int kns_oracle_process(kns_oracle_t *o, int num_frames, const int16_t *pcm, int16_t *enhanced, int num_threads);
+
+/* streams per block used by the last kns_oracle_process call (reporting only) */
+int kns_oracle_last_block(void);
 
 /* single stream (index s), one frame, with taps */
 int kns_oracle_process_tap(kns_oracle_t *o, int s, const int16_t *pcm, int16_t *enhanced, kns_taps_t *taps);

@@ -53,6 +53,11 @@ def lib():
     return _lib
 
 
+def block_size() -> int:
+    """Streams per weight pass in the last `Oracle.process` call (reporting only)."""
+    return int(lib().kns_oracle_last_block())
+
+
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 

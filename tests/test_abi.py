@@ -186,7 +186,80 @@ def test_koala_error_formatting():
 
 def test_model_file_checks(lib, tmp_path):
     bad = tmp_path / 'bad.kns'
-    bad.write_bytes(b'koala3.0.0' + bytes(64))
+    bad.write_bytes(b'KNS0\0\0\0\0' + bytes(64))
     h = C.c_void_p()
     assert lib.pv_koala_init(b'key', str(bad).encode(), b'best', C.byref(h)) == 2
     assert 'not a Koala (KNS1) model file' in stack(lib)[1][0]
+
+
+_HIDDEN_GPU_SCRIPT = r'''
+import json, sys
+sys.path.insert(0, %(root)r)
+import koala_amd
+res = {}
+def attempt(name, **kw):
+    args = dict(access_key='reference-binding-check')
+    args.update(kw)
+    try:
+        koala_amd.create(**args).delete()
+        res[name] = {'exception': None}
+    except Exception as e:
+        res[name] = {'exception': type(e).__name__, 'str': str(e), 'message_stack': list(getattr(e, 'message_stack', []) or [])}
+attempt('init_no_gpu_best')
+attempt('init_no_gpu_gpu0', device='gpu:0')
+attempt('init_bad_device', device='foo')
+attempt('init_cpu_device', device='cpu:1')
+attempt('init_missing_model_python_side', model_path='/nope.kns')
+attempt('init_empty_key_python_side', access_key='')
+attempt('init_missing_library_python_side', library_path='/nope.so')
+res['list_hardware_devices'] = list(koala_amd.available_devices())
+print('CAPTURE', json.dumps(res))
+'''
+
+
+def test_own_binding_shows_a_caller_what_the_reference_binding_shows():
+    """tests/golden/reference_binding_capture.json is what the REFERENCE's unmodified binding/python/_koala.py reports when it
+    is pointed at this library on a box without a GPU (tools/check_reference_binding.py, build container only).  koala_amd's
+    own binding must give a caller the same exception types, str() texts and message stacks.  Runs with the GPUs hidden, so
+    it checks the same thing here and on the GPU box."""
+    import subprocess
+    import sys
+    with open(os.path.join(GOLDEN, 'reference_binding_capture.json')) as f:
+        cap = json.load(f)
+    assert all(cap['symbols_resolved'].values())
+    env = dict(os.environ, HIP_VISIBLE_DEVICES='-1', ROCR_VISIBLE_DEVICES='-1')
+    out = subprocess.run([sys.executable, '-c', _HIDDEN_GPU_SCRIPT % {'root': ROOT}], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('CAPTURE')][-1][8:])
+    for name in ('init_no_gpu_best', 'init_no_gpu_gpu0', 'init_bad_device', 'init_cpu_device',
+                 'init_missing_model_python_side', 'init_empty_key_python_side', 'init_missing_library_python_side'):
+        assert got[name]['exception'] == cap[name]['exception'], name
+        assert got[name]['str'] == cap[name]['str'], name
+        assert got[name]['message_stack'] == cap[name]['message_stack'], name
+    assert got['list_hardware_devices'] == cap['list_hardware_devices'] == []
+
+
+def test_reference_pv_model_gets_a_dedicated_error(lib, tmp_path):
+    """A reference `.pv` parameter file (magic `koala3.0.0`, SURVEY App. B) is recognised and refused by name, not with
+    the generic read error."""
+    fake = tmp_path / 'koala_params.pv'
+    fake.write_bytes(b'koala3.0.0' + bytes(5) + bytes(4096))
+    h = C.c_void_p()
+    st = lib.pv_koala_init(b'key', str(fake).encode(), b'best', C.byref(h))
+    assert st == 2  # PV_STATUS_IO_ERROR
+    _, msgs = stack(lib)
+    assert 'reference Koala `.pv` model' in msgs[0] and 'not supported' in msgs[0]
+
+
+def test_listed_device_strings_are_accepted_back(lib, random_model):
+    """pv_koala_list_hardware_devices prints `gpu:N - <name>`; create(device=<that string>) must parse (it may then fail for
+    lack of a GPU, but never as `not a valid device string`)."""
+    h = C.c_void_p()
+    st = lib.pv_koala_init(b'key', random_model.encode(), b'gpu:0 - AMD Instinct MI355X', C.byref(h))
+    _, msgs = stack(lib)
+    assert not any('not a valid device string' in m for m in msgs)
+    if st == 0:
+        lib.pv_koala_delete(h)
+    st = lib.pv_koala_init(b'key', random_model.encode(), b' - x', C.byref(h))
+    assert st == 3 and 'not a valid device string' in stack(lib)[1][0]

@@ -443,3 +443,38 @@ def test_host_calls_on_a_caller_stream(random_model):
     kb.set_stream(0)
     kb.delete()
     assert np.array_equal(own[0], mine[0]) and np.array_equal(own[1], mine[1])
+
+
+@pytest.mark.parametrize('T,calls', [(1, 3), (32, 2)])
+def test_baseline_config1_b256_fp32_at_its_stated_size(random_model, T, calls):
+    """BASELINE configs[1] exactly: 256 streams, fp32 mask network -- one frame per call (16 m-tiles: the single-launch
+    low-latency layers) and 32 frames per call (the frame-by-frame fp32 layers).  Every stream against the oracle."""
+    B = 256
+    x = synth_streams(B, T * calls, seed=256)
+    kb = koala_amd.create_batch('key', B, T, 'fp32', model_path=random_model)
+    ref = oracle.Oracle(random_model, B)
+    for c in range(calls):
+        xc = np.ascontiguousarray(x[:, c * T * 256:(c + 1) * T * 256])
+        d = lsb(kb.process(xc), ref.process(xc))
+        assert d.max() <= 1 and (d == 0).mean() > 0.97, (c, int(d.max()))
+    kb.delete()
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('B,T', [(256, 1), (272, 1), (3072, 2), (3088, 2)])
+def test_dispatch_boundaries(random_model, precision, B, T):
+    """The engine switches kernel families at 16 -> 17 m-tiles (one frame: low-latency layer kernel vs input GEMM +
+    recurrent kernel) and at 192 -> 193 m-tiles (fp32, several frames: frame-by-frame layers vs chunked recurrence),
+    kns_engine.cpp run_device().  Both sides of both edges, two calls each, every stream against the oracle."""
+    base = synth_streams(128, 2 * T, seed=B)
+    x = np.tile(base, ((B + 127) // 128, 1))[:B]
+    kb = koala_amd.create_batch('key', B, T, precision, model_path=random_model)
+    ref = oracle.Oracle(random_model, 128, oracle.PREC_BF16 if precision == 'bf16' else oracle.PREC_FP32)
+    tol = 6 if precision == 'bf16' else 1
+    for c in range(2):
+        y = kb.process(np.ascontiguousarray(x[:, c * T * 256:(c + 1) * T * 256]))
+        want = ref.process(np.ascontiguousarray(base[:, c * T * 256:(c + 1) * T * 256]))
+        assert lsb(y[:128], want).max() <= tol
+        for i in range(128, B):  # replicas in other m-tiles (the last one ragged at 272 / 3088) are bit-identical
+            assert np.array_equal(y[i], y[i % 128]), i
+    kb.delete()

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, frame_rms, synth_streams
+from conftest import GOLDEN, ROOT, frame_rms, synth_streams
 from oracle import oracle
 
 
@@ -167,3 +167,24 @@ def test_oracle_reproduces_committed_golden_vectors(random_model, gate_model):
             # bit-exact on the host that wrote them; another libm may move the window/twiddle tables by an ulp
             assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
             assert (got == want).mean() > 0.999
+
+
+def test_blocked_gemm_equals_the_plain_statement(random_model, tmp_path):
+    """The oracle's register-blocked GEMM advances the same k-ascending fmaf chains as the plain triple loop
+    (KNS_ORACLE_SIMPLE_GEMM=1 selects it): the PCM must agree bit for bit, in both precision modes, for ragged
+    stream counts (row groups of 6 + remainder, blocks of up to 64 streams)."""
+    import subprocess
+    import sys
+    script = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from oracle import oracle\n"
+        "from koala_amd.workload import synth_streams\n"
+        "x = synth_streams(71, 3, seed=9)\n"
+        "for prec in (0, 1):\n"
+        "    np.save(sys.argv[1] + '_%%d.npy' %% prec, oracle.Oracle(%r, 71, prec).process(x, num_threads=1))\n"
+    ) % (ROOT, os.path.join(ROOT, 'tests'), random_model)
+    for tag, env in (('blocked', {}), ('simple', {'KNS_ORACLE_SIMPLE_GEMM': '1'})):
+        subprocess.run([sys.executable, '-c', script, str(tmp_path / tag)], env=dict(os.environ, **env), check=True, timeout=600)
+    for prec in (0, 1):
+        assert np.array_equal(np.load(tmp_path / ('blocked_%d.npy' % prec)), np.load(tmp_path / ('simple_%d.npy' % prec)))

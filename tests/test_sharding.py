@@ -71,3 +71,14 @@ def test_two_ranks_gloo(tmp_path):
     assert np.array_equal(got, whole)
     frames, elapsed = (tmp_path / 'agg.txt').read_text().split()
     assert int(frames) == 50 and abs(float(elapsed) - 2.0) < 1e-9
+
+
+def test_bench_refuses_a_world_size_it_was_not_asked_for():
+    """`--gpus N` must describe the job that ran: a launcher-provided WORLD_SIZE that differs is an error, not a line."""
+    env = dict(os.environ, WORLD_SIZE='4', RANK='0', LOCAL_RANK='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode == 2 and 'WORLD_SIZE=4' in out.stderr and not out.stdout.strip()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1'], env=env, capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode == 2
