@@ -274,7 +274,7 @@ def test_alternative_kernels_give_identical_pcm(random_model):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = _SWITCH_SCRIPT % {'root': root, 'tests': os.path.join(root, 'tests'), 'model': random_model}
     digests = {}
-    for switch in ('', 'KOALA_AMD_GRU_STREAM', 'KOALA_AMD_GRU_4WAVE', 'KOALA_AMD_GEMM_GENERIC', 'KOALA_AMD_GEMM_WS1',
+    for switch in ('', 'KOALA_AMD_GRU_STREAM', 'KOALA_AMD_GEMM_GENERIC', 'KOALA_AMD_GEMM_WS1',
                    'KOALA_AMD_GEMM_NO_WSR', 'KOALA_AMD_NO_SMALL', 'KOALA_AMD_NO_GRAPH'):
         env = dict(os.environ)
         if switch:

@@ -1,15 +1,8 @@
-#!/bin/bash
-# Developer tool: build variant libraries with -D switches and time the kernel classes of each (run through gpurun).
-#   tools/ab.sh "" -DR8X_NO_HSEQ "-DR8X_NO_T16 -DR8X_NO_GI"
-cd "$(dirname "$0")/.."
-mkdir -p build/ab
-i=0
-for flags in "$@"; do
-  lib=build/ab/lib$i.so
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off $flags -x hip \
-      koala_amd/csrc/kns_stft.hip koala_amd/csrc/kns_gemm.hip koala_amd/csrc/kns_gru.hip koala_amd/csrc/kns_engine.cpp \
-      koala_amd/csrc/pv_api.cpp -shared -o $lib || exit 1
-  echo "== variant $i: '$flags'"
-  SWEEP_LIB=$PWD/$lib SWEEP_T=${AB_T:-32} python tools/sweep.py 2>&1 | grep "^T="
-  i=$((i+1))
+for rep in 1 2; do
+  for lib in build/libpv_koala_r1gru.so build/libpv_koala_pubtop.so koala_amd/lib/libpv_koala.so; do
+    python bench.py --library $PWD/$lib --no-cpu-baseline --no-extra --steps 400 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$lib rep $rep: %.2f Mframes/s  %.4f ms/step | ' % (d['value']/1e6, d['ms_per_step']) + '  '.join('%s %.1f' % (k, v['avg_launch_ms']*1e3) for k,v in d['stages'].items()))"
+  done
 done
