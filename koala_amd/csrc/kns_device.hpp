@@ -180,42 +180,101 @@ __device__ __forceinline__ void radix4(cpx (&v)[4]) {
     v[3] = csub(a1, a3);
 }
 
-// LDS exchange buffers of the wave FFT: two ping-pong arrays of 256 interleaved complex values (ds_read/write_b64
-// straight into the packed register pairs).  Padding them against the 4-way write conflicts of the first two radix-4
-// stages was measured SLOWER on MI355X (synthesis 246 vs 193 us): the extra address VALU costs more than the conflicts.
-constexpr int kFftBufFloats = 4 * 256;  // per wave: 2 buffers x 256 complex
+// ---- FFT-256 of FOUR frames per wavefront: a row of 16 lanes owns one frame, a lane 16 complex points.
+// 256 = 16 x 16: a 16-point DFT in registers (two radix-4 levels), the W_256 twiddles, ONE 16 x 16 transpose among the
+// row's lanes through LDS, a second 16-point DFT in registers.  Index maps:
+//   input   v[j]  = z[16 j + c]                       (stride-16 points: the first DFT needs no exchange)
+//   output  v[k2] = Z[c + 16 k2]                      (the same map: an FFT's output feeds the next FFT as it is)
+// with c = fft_column(lane), the lane's column in its row.
+// Against the one-frame-per-wave radix-4 Stockham form this replaces (four exchanges per frame, 4-way bank conflicts on
+// two of them) a frame crosses LDS once, at addresses that are the same for every frame (a padded [16][17] tile per row:
+// conflict-free both ways, all offsets immediate).
+constexpr int kFftRowBytes = 16 * 17 * 8;            // one frame's exchange tile
+constexpr int kFftWaveBytes = 4 * kFftRowBytes;      // per wave
 
-// Forward 256-point complex FFT of one wavefront, radix-4 Stockham autosort.  On entry v[r] = z[lane + 64 r].
-// `buf` is this wave's LDS scratch (kFftBufFloats floats).  On return the spectrum is in natural order in the first
-// buffer (((cpx *) buf)[k]) and visible to the whole wave.  tw = exp(-2 pi i k / 512), k = 0..511, in LDS.
-__device__ __forceinline__ void fft256_wave(cpx (&v)[4], float *buf, const float2 *tw, int lane) {
-    cpx *b0 = (cpx *) buf, *b1 = (cpx *) buf + 256;
-    // stage Ns = 1 (all twiddles are 1)
-    radix4(v);
+// natural order in, natural order out; forward transform (W = exp(-2 pi i / 16))
+__device__ __forceinline__ void dft16(cpx (&x)[16]) {
+    constexpr float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, c2 = 0.70710678118654752f;
+    cpx u[4][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) b1[4 * lane + r] = v[r];
-    wave_lds_sync();
-    // stages Ns = 4, 16, 64
+    for (int b = 0; b < 4; ++b) {
+        cpx q[4] = {x[b], x[4 + b], x[8 + b], x[12 + b]};
+        radix4(q);
 #pragma unroll
-    for (int s = 1; s < 4; ++s) {
-        const int Ns = 1 << (2 * s);
-        cpx *src = (s & 1) ? b1 : b0;
-        cpx *dst = (s & 1) ? b0 : b1;
-        const int k = lane & (Ns - 1);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = src[lane + 64 * r];
-#pragma unroll
-        for (int r = 1; r < 4; ++r) {
-            float2 w = tw[r * k * (128 / Ns)];
-            v[r] = cmul(v[r], cpx{w.x, w.y});
-        }
-        radix4(v);
-        const int j0 = (lane / Ns) * Ns * 4 + k;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dst[j0 + r * Ns] = v[r];
-        wave_lds_sync();
+        for (int c = 0; c < 4; ++c) u[b][c] = q[c];
     }
-    // s = 1 -> b0, s = 2 -> b1, s = 3 -> b0: result is in b0
+    // u[b][c] *= W_16^(b c)
+    u[1][1] = cmul(u[1][1], cpx{c1, -s1});
+    u[1][2] = cpx{(u[1][2].x + u[1][2].y) * c2, (u[1][2].y - u[1][2].x) * c2};
+    u[1][3] = cmul(u[1][3], cpx{s1, -c1});
+    u[2][1] = cpx{(u[2][1].x + u[2][1].y) * c2, (u[2][1].y - u[2][1].x) * c2};
+    u[2][2] = cpx{u[2][2].y, -u[2][2].x};
+    u[2][3] = cpx{(u[2][3].y - u[2][3].x) * c2, -((u[2][3].x + u[2][3].y) * c2)};
+    u[3][1] = cmul(u[3][1], cpx{s1, -c1});
+    u[3][2] = cpx{(u[3][2].y - u[3][2].x) * c2, -((u[3][2].x + u[3][2].y) * c2)};
+    u[3][3] = cmul(u[3][3], cpx{-c1, s1});
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        cpx q[4] = {u[0][c], u[1][c], u[2][c], u[3][c]};
+        radix4(q);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) x[c + 4 * d] = q[d];
+    }
+}
+
+// Column of a row's lane: the 16 columns c = 0..15 sit on the lanes so that the two columns c and 16 - c, which hold each
+// other's mirrored bins (k <-> 256 - k), are NEIGHBOURS: lanes (2, 3) = columns (1, 15), (4, 5) = (2, 14) ... (14, 15) =
+// (7, 9), and lanes 0, 1 = the self-paired columns 0 and 8.  The mirrored-bin exchange is then one quad_perm DPP move
+// per register (a wavefront shuffle, no LDS).
+__device__ __forceinline__ int fft_column(int lane) {
+    const int l = lane & 15;
+    return (l & 1) ? (l == 1 ? 8 : 16 - (l >> 1)) : (l >> 1);
+}
+
+// twl: this lane's view of the LDS table [k1][column] of exp(-2 pi i column k1 / 256) (fft_fill_twiddles); xw / xr: this
+// lane's write and read base inside the wave's exchange tiles (fft_lane_bases); all offsets below are immediates
+__device__ __forceinline__ void fft256_rows(cpx (&v)[16], const char *twl, char *xw, const char *xr) {
+    dft16(v);
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmul(v[k1], *(const cpx *) (twl + k1 * 128));
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) *(cpx *) (xw + k1 * 136) = v[k1];  // element (k1, c) of the row's [16][17] tile
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = *(const cpx *) (xr + j * 8);   // element (c, j)
+    wave_lds_sync();
+    dft16(v);
+}
+
+constexpr int kFftTwiddleBytes = 16 * 16 * 8;
+
+// tw512: exp(-2 pi i k / 512), k = 0..511 (anywhere); dst: LDS, kFftTwiddleBytes
+__device__ __forceinline__ void fft_fill_twiddles(char *dst, const float2 *tw512, int tid, int nthreads) {
+    for (int i = tid; i < 256; i += nthreads) ((float2 *) dst)[i] = tw512[2 * (((i & 15) * (i >> 4)) & 255)];
+}
+
+__device__ __forceinline__ void fft_lane_bases(char *wave_buf, const char *twl, int lane, char **xw, const char **xr,
+                                               const char **tw_lane) {
+    const int c = fft_column(lane), q = lane >> 4;
+    *xw = wave_buf + q * kFftRowBytes + c * 8;
+    *xr = wave_buf + q * kFftRowBytes + c * 136;
+    *tw_lane = twl + c * 8;
+}
+
+// value of the same register in the neighbouring lane (lane ^ 1)
+__device__ __forceinline__ float lane_pair(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true));
+}
+
+// p[k2] = a at index 256 - k, k = c + 16 k2 (index 0 pairs with itself): the neighbouring lane (column 16 - c) holds it in
+// register 15 - k2; column 0 holds its own in register 16 - k2, column 8 in register 15 - k2
+__device__ __forceinline__ void fft_partner(const cpx (&a)[16], cpx (&p)[16], int c) {
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) {
+        const cpx t = {lane_pair(a[15 - k2].x), lane_pair(a[15 - k2].y)};
+        const cpx own = c == 0 ? a[(16 - k2) & 15] : a[15 - k2];
+        p[k2] = (c & 7) == 0 ? own : t;
+    }
 }
 
 constexpr int kGruTilesPerWave = 5;  // 17 unit tiles over 4 waves: 5,4,4,4

@@ -240,6 +240,8 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     use_graph_ = getenv("KOALA_AMD_NO_GRAPH") == nullptr;
     no_small_ = getenv("KOALA_AMD_NO_SMALL") != nullptr;          // developer switches, read once (not per frame)
     no_zero_copy_ = getenv("KOALA_AMD_NO_ZERO_COPY") != nullptr;
+    no_recompute_ = getenv("KOALA_AMD_STORE_SPECTRUM") != nullptr;  // A/B switch: spectrum through HBM in every call
+    debug_taps_ = getenv("KOALA_AMD_DEBUG_TAPS") != nullptr;        // keep every intermediate debug_read() can return
     // host-pointer calls are cut into sub-chunks of host_chunk_ frames (two staging slots = the Tmax-sized buffers)
     host_chunk_ = Tmax_ / 2 < 1 ? 1 : (Tmax_ / 2 > 16 ? 16 : Tmax_ / 2);
     host_pipeline_min_bytes_ = (size_t) 4 << 20;  // below this a call is launch-bound: sub-chunks would only add launches
@@ -498,6 +500,17 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     an.T = T;
     an.nbf = nbf_;
     an.precision = prec_;
+    // The spectrum makes its round trip through HBM only where it has to: in single-frame calls (the history is updated in
+    // place there, so the synthesis kernel cannot rebuild it) and when the debug taps are on.  Otherwise the synthesis
+    // kernel recomputes it from the PCM.
+    const bool recompute = !in_place && !no_recompute_;
+    an.write_spec = !recompute || debug_taps_;
+    {   // time segments: about four workgroups per CU
+        int seg = T;
+        while (seg > 4 && (Bpad_ / 16) * ((T + seg - 1) / seg) < 1024) seg = (seg + 1) / 2;
+        an.seg = seg;
+    }
+    const int16_t *hist_before = d_hist_[hist_cur_];
     // developer switch (power / clock probing, results are garbage): launch only the kernels of one class
     static const int only = getenv("KOALA_AMD_ONLY_CLASS") ? atoi(getenv("KOALA_AMD_ONLY_CLASS")) : -1;
     tick(kClsAnalysis);
@@ -614,6 +627,9 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     const int seg = seg_env > 0 ? seg_env : seg_auto;
     sy.seg = T <= seg ? T : seg;
     sy.out = d_out;
+    sy.pcm = d_pcm;
+    sy.hist_in = hist_before;
+    sy.recompute = recompute;
     sy.B = B_;
     sy.Bpad = Bpad_;
     sy.T = T;
@@ -858,8 +874,12 @@ int64_t Engine::debug_read(int what, float *out, int64_t capacity, std::string *
             for (int b = 0; b < B_; ++b) {
                 const float *src = s + ((size_t) t * Bpad_ + b) * 512;
                 float *dst = out + ((size_t) t * B_ + b) * kBins * 2;
-                memcpy(dst, src, 512 * 4);
-                dst[512] = src[1];  // Nyquist travels in the imaginary slot of bin 0
+                for (int k = 0; k < 256; ++k) {  // un-permute the kernels' lane order (kns_kernels.h)
+                    const int c = k & 15, k2 = k >> 4, slot = ((k2 >> 1) * 16 + c) * 2 + (k2 & 1);
+                    dst[2 * k] = src[2 * slot];
+                    dst[2 * k + 1] = src[2 * slot + 1];
+                }
+                dst[512] = dst[1];  // Nyquist travels in the imaginary slot of bin 0
                 dst[513] = 0.0f;
                 dst[1] = 0.0f;
             }

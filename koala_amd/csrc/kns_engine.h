@@ -99,7 +99,7 @@ private:
 
     // hipGraph of one host-pointer frame (copy-in, 23 kernels, copy-out); built on first use
     hipGraphExec_t frame_graph_[8] = {};  // one per combination of the hidden-state / history / tail ping-pong indices
-    bool use_graph_ = true, no_small_ = false, no_zero_copy_ = false;
+    bool use_graph_ = true, no_small_ = false, no_zero_copy_ = false, no_recompute_ = false, debug_taps_ = false;
 
     // profiling
     bool profiling_ = false;

@@ -17,9 +17,12 @@ struct AnalysisArgs {
     const float *twiddle;     // [512][2] exp(-2 pi i k / 512)
     const float *mean;        // [257]
     const float *scale;       // [257]
-    float *spec;              // [T][Bpad][256][2] packed half spectrum (slot 0 = {X0.re, X256.re})
+    float *spec;              // [T][Bpad][256][2] packed half spectrum (bin 0 = {X0.re, X256.re}); bin k = c + 16 k2 sits at
+                              // complex slot ((k2 >> 1) * 16 + c) * 2 + (k2 & 1): the STFT kernels' lane order
     void *feat;               // A-packed [T*mtiles][nbf] blocks
     int B, Bpad, T, nbf, precision;
+    int seg;         // frames per workgroup (a workgroup walks a time segment of its 16 streams)
+    int write_spec;  // 0: the synthesis kernel rebuilds the spectrum from the PCM, nothing is stored
 };
 void launch_analysis(const AnalysisArgs &a, hipStream_t s);
 
@@ -34,6 +37,9 @@ struct SynthesisArgs {
     int16_t *out;           // [B][T*256]
     int B, Bpad, T;
     int seg;                // frames per workgroup; segments after the first replay one frame to rebuild the tail
+    const int16_t *pcm;     // recompute != 0: the call's input [B][T*256] ...
+    const int16_t *hist_in; // ... and the history the analysis kernel started from, [Bpad][256]
+    int recompute;          // rebuild each frame's spectrum from its PCM instead of reading `spec`
 };
 void launch_synthesis(const SynthesisArgs &a, hipStream_t s);
 

@@ -4,290 +4,344 @@
 
 namespace kns {
 
+// ------------------------------------------------------------------------------------------------ shared pieces
+
+// One row of 16 lanes owns one stream; a wave four streams; a workgroup (4 waves) the 16 streams of an m-tile.
+// The lane in column c of its row (c = fft_column(lane), kns_device.hpp) holds the 16 points n = c + 16 j of whatever
+// 256-point complex sequence is live: packed samples z[n] = x[2n] + i x[2n+1], FFT bins, inverse-FFT input.  Every table
+// the lane needs is indexed by such n, so it sits in LDS in natural order and is read at (lane base + immediate offset).
+constexpr int kOffTw = 0;                               // float2[512]: exp(-2 pi i k / 512)
+constexpr int kOffWin = 4096;                           // float[512]:  sin(pi n / 512)
+constexpr int kOffTwl = kOffWin + 2048;                 // fft_fill_twiddles table
+constexpr int kOffXbuf = kOffTwl + kFftTwiddleBytes;    // 4 waves x kFftWaveBytes
+constexpr int kOffStftEnd = kOffXbuf + 4 * kFftWaveBytes;
+
+__device__ __forceinline__ void stft_load_tables(char *smem, const float *twiddle, const float *window, int tid) {
+    float2 *tw = (float2 *) (smem + kOffTw);
+    float *win = (float *) (smem + kOffWin);
+    for (int i = tid; i < 512; i += 256) {
+        tw[i] = ((const float2 *) twiddle)[i];
+        win[i] = window[i];
+    }
+    fft_fill_twiddles(smem + kOffTwl, (const float2 *) twiddle, tid, 256);
+}
+
+// the eight dwords (sample pairs) this lane owns of one 256-sample frame: pairs 16 jj + c
+__device__ __forceinline__ void load_frame(int (&f)[8], const int16_t *frame, int c) {
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) f[jj] = ((const int *) frame)[16 * jj + c];
+}
+
+// windowed packed samples of the 512-sample analysis block [prev | cur]; win_c = LDS window + 8 c
+__device__ __forceinline__ void window_block(cpx (&v)[16], const int (&prev)[8], const int (&cur)[8], const char *win_c) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int pr = j < 8 ? prev[j] : cur[j - 8];
+        const float2 w = *(const float2 *) (win_c + j * 128);  // window[2n], window[2n + 1], n = 16 j + c
+        const float lo = (float) (int16_t) (pr & 0xffff), hi = (float) (int16_t) (pr >> 16);
+        v[j].x = (lo * (1.0f / 32768.0f)) * w.x;
+        v[j].y = (hi * (1.0f / 32768.0f)) * w.y;
+    }
+}
+
+// Half spectrum of the real 512-point block from the 256-point FFT Z of its packed samples: X[k], k = c + 16 k2.
+// Bin 0 carries {X[0], X[256]} (both real).  The arithmetic is the same in the analysis and the synthesis kernel, so a
+// spectrum that is recomputed instead of stored is the stored one bit for bit.  tw_c = LDS exp(-2 pi i k / 512) + 8 c.
+__device__ __forceinline__ void real_spectrum(const cpx (&z)[16], cpx (&x)[16], const char *tw_c, int c) {
+    cpx zp[16];
+    fft_partner(z, zp, c);
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) {
+        const cpx zk = z[k2];
+        const float2 w = *(const float2 *) (tw_c + k2 * 128);
+        // s = Z[k] + conj(Z[256 - k]), d = Z[k] - conj(Z[256 - k])
+        const cpx s = {zk.x + zp[k2].x, zk.y - zp[k2].y}, d = {zk.x - zp[k2].x, zk.y + zp[k2].y};
+        const cpx p = cmul(d, cpx{w.x, w.y});
+        cpx r = {0.5f * (s.x + p.y), 0.5f * (s.y - p.x)};
+        if (k2 == 0 && c == 0) r = cpx{zk.x + zk.y, zk.x - zk.y};
+        x[k2] = r;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ analysis
 
 template <class P>
+__device__ __forceinline__ float feature_log(float x) {
+    // fp32 configuration: the spec's polynomial (bit-comparable with the oracle).  bf16 configuration: the feature is
+    // rounded to bf16 (8 bits) right after, so the hardware logarithm (1 ulp) is what the tolerance-specified mode uses.
+    if (P::kPrec == kBf16) return __builtin_amdgcn_logf(x) * 0.693147180559945309f;
+    return kns_log(x);
+}
+
+// grid (stream tiles, time segments): a workgroup walks the frames [t0, t1) of its 16 streams, so every PCM sample is
+// read once (the previous frame stays in registers) and the per-lane constants are set up once per segment.
+template <class P, bool kSpec>
 __global__ __launch_bounds__(256) void analysis_kernel(AnalysisArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2 *tw = (float2 *) smem;                         // 4 KiB
-    float *win = (float *) (smem + 4096);                 // 2 KiB
-    float *fftbuf = (float *) (smem + 6144);              // 4 waves x kFftBufFloats
-    typename P::elem_t *tile = (typename P::elem_t *) (smem + 6144 + 4 * kFftBufFloats * 4);  // nbf KiB, A-packed feature tile
+    float *lmean = (float *) (smem + kOffStftEnd), *lscale = lmean + 272;
+    typename P::elem_t *tile0 = (typename P::elem_t *) (smem + kOffStftEnd + 2 * 272 * 4);  // 2 x nbf KiB
+    const int tile_elems = g.nbf * 64 * P::EPL;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mt = blockIdx.x, t = blockIdx.y;
-    const int mtiles = g.Bpad >> 4;
-
-    // all 16 sample loads of this wave's four frames go out before anything else: the kernel is latency-bound on them
+    const int c = fft_column(lane), q = lane >> 4, row = wave * 4 + q;
+    const int mt = blockIdx.x, mtiles = g.Bpad >> 4;
+    const int t0 = blockIdx.y * g.seg, t1 = min(g.T, t0 + g.seg);
+    const int b = mt * 16 + row;
     const size_t row_len = (size_t) g.T * kFrame;
-    int raw[4][4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
-        const int b = mt * 16 + wave * 4 + f;
-        const int16_t *cur = g.pcm + (size_t) b * row_len + (size_t) t * kFrame;
-        const int16_t *old = (t == 0) ? g.hist_in + (size_t) b * kFrame : cur - kFrame;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = lane + 64 * r;
-            const int16_t *src = (r < 2) ? old + 2 * n : cur + 2 * (n - 128);
-            raw[f][r] = (b < g.B) ? *(const int *) src : 0;
-        }
+    // rows past the last stream (ragged last tile) read the last stream's samples: their results are never stored
+    // anywhere a stream would see them, and the loop carries no conditional vector-memory operation
+    const int16_t *pcm_row = g.pcm + (size_t) (b < g.B ? b : g.B - 1) * row_len;
+
+    int prev[8], cur[8], nxt[8];
+    load_frame(prev, t0 == 0 ? g.hist_in + (size_t) b * kFrame : pcm_row + (size_t) (t0 - 1) * kFrame, c);
+    load_frame(cur, pcm_row + (size_t) t0 * kFrame, c);
+    stft_load_tables(smem, g.twiddle, g.window, tid);
+    for (int i = tid; i < kBins; i += 256) {
+        lmean[i] = g.mean[i];
+        lscale[i] = g.scale[i];
     }
-    for (int i = tid; i < 512; i += 256) {
-        tw[i] = ((const float2 *) g.twiddle)[i];
-        win[i] = g.window[i];
-    }
-    // the normalisation constants of this lane's bins, once: loaded inside the frame loop they sit behind the spectrum
-    // stores in the vector-memory queue, and waiting for them means waiting for the stores' acknowledgements
-    float nmean[4], nscale[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        nmean[r] = g.mean[lane + 64 * r];
-        nscale[r] = g.scale[lane + 64 * r];
-    }
-    const float nmean_nyq = g.mean[256], nscale_nyq = g.scale[256];
     {
-        uint4 *z = (uint4 *) tile;
-        for (int i = tid; i < g.nbf * 64; i += 256) z[i] = uint4{0, 0, 0, 0};
+        uint4 *z = (uint4 *) tile0;
+        for (int i = tid; i < 2 * g.nbf * 64; i += 256) z[i] = uint4{0, 0, 0, 0};
     }
     __syncthreads();
+    char *xw;
+    const char *xr, *twl_c;
+    fft_lane_bases(smem + kOffXbuf + wave * kFftWaveBytes, smem + kOffTwl, lane, &xw, &xr, &twl_c);
+    const char *tw_c = smem + kOffTw + c * 8, *win_c = smem + kOffWin + c * 8;
+    const float *mean_c = lmean + c, *scale_c = lscale + c;
 
-    float *buf = fftbuf + wave * kFftBufFloats;
-
+    for (int t = t0; t < t1; ++t) {
+        // next frame's samples are requested before this frame is transformed (clamped, never skipped)
+        load_frame(nxt, pcm_row + (size_t) (t + 1 < t1 ? t + 1 : t) * kFrame, c);
+        cpx v[16];
+        window_block(v, prev, cur, win_c);
+        fft256_rows(v, twl_c, xw, xr);
+        cpx x[16];
+        real_spectrum(v, x, tw_c, c);
+        typename P::elem_t *tile = tile0 + (t & 1) * tile_elems;
+        if (kSpec) {
+            // stored in the lane order of this kernel pair: bins (c + 16 k2, c + 16 (k2 + 1)), k2 even, as one 16-byte word
+            // at [(k2 / 2) * 16 + c] -- a row of lanes moves 256 contiguous bytes per instruction
+            f32x4 *spec = (f32x4 *) g.spec + ((size_t) t * g.Bpad + b) * 128;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-        const int row = wave * 4 + f;
-        const int b = mt * 16 + row;
-        cpx v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = lane + 64 * r;
-            const int pr = raw[f][r];
-            float lo = (float) (int16_t) (pr & 0xffff), hi = (float) (int16_t) (pr >> 16);
-            v[r].x = (lo * (1.0f / 32768.0f)) * win[2 * n];
-            v[r].y = (hi * (1.0f / 32768.0f)) * win[2 * n + 1];
+            for (int k2 = 0; k2 < 16; k2 += 2) spec[(k2 >> 1) * 16 + c] = f32x4{x[k2].x, x[k2].y, x[k2 + 1].x, x[k2 + 1].y};
         }
-        if (t == g.T - 1 && b < g.Bpad) {
-            int *h = (int *) (g.hist_out + (size_t) b * kFrame);
-            h[lane] = raw[f][2];
-            h[lane + 64] = raw[f][3];
-        }
-        fft256_wave(v, buf, tw, lane);
-        float2 *spec = (float2 *) g.spec + ((size_t) t * g.Bpad + b) * 256;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = lane + 64 * r;
-            const int kc = (256 - k) & 255;
-            const cpx zk = ((const cpx *) buf)[k];
-            cpx zc = ((const cpx *) buf)[kc];
-            zc.y = -zc.y;
-            float2 w = tw[k];
-            cpx s = cadd(zk, zc), d = csub(zk, zc);
-            cpx p = cmul(d, cpx{w.x, w.y});
-            float xr = 0.5f * (s.x + p.y);
-            float xi = 0.5f * (s.y - p.x);
-            float pw = __builtin_fmaf(xr, xr, xi * xi);
-            float nyq = 0.0f;
-            if (k == 0) {  // DC and Nyquist share packed slot 0
-                xr = zk.x + zk.y;
-                nyq = zk.x - zk.y;
-                xi = nyq;
-                pw = xr * xr;
-            }
-            spec[k] = float2{xr, xi};
-            float ft = (kns_log(pw + 1e-10f) - nmean[r]) * nscale[r];
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const int k = c + 16 * k2;
+            float pw = __builtin_fmaf(x[k2].x, x[k2].x, x[k2].y * x[k2].y);
+            if (k2 == 0 && c == 0) pw = x[k2].x * x[k2].x;
+            const float ft = (feature_log<P>(pw + 1e-10f) - mean_c[16 * k2]) * scale_c[16 * k2];
             tile[(k / P::KB) * 64 * P::EPL + P::off(row, k % P::KB)] = P::cvt(ft);
-            if (k == 0) {
-                float fn = (kns_log(nyq * nyq + 1e-10f) - nmean_nyq) * nscale_nyq;
-                tile[(256 / P::KB) * 64 * P::EPL + P::off(row, 256 % P::KB)] = P::cvt(fn);
-            }
         }
-        wave_lds_sync();
+        if (c == 0) {  // Nyquist bin: the imaginary slot of bin 0
+            const float nyq = x[0].y;
+            const float fn = (feature_log<P>(nyq * nyq + 1e-10f) - lmean[256]) * lscale[256];
+            tile[(256 / P::KB) * 64 * P::EPL + P::off(row, 256 % P::KB)] = P::cvt(fn);
+        }
+        __syncthreads();  // (one barrier per frame: the two tiles alternate)
+        {
+            const uint4 *src = (const uint4 *) tile;
+            uint4 *dst = (uint4 *) g.feat + ((size_t) t * mtiles + mt) * g.nbf * 64;
+            for (int i = tid; i < g.nbf * 64; i += 256) dst[i] = src[i];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            prev[jj] = cur[jj];
+            cur[jj] = nxt[jj];
+        }
     }
-    __syncthreads();
-    {
-        const uint4 *src = (const uint4 *) tile;
-        uint4 *dst = (uint4 *) g.feat + ((size_t) t * mtiles + mt) * g.nbf * 64;
-        for (int i = tid; i < g.nbf * 64; i += 256) dst[i] = src[i];
+    if (t1 == g.T && b < g.B) {  // history for the next call: the last frame (prev after the final rotation)
+        int *h = (int *) (g.hist_out + (size_t) b * kFrame);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) h[16 * jj + c] = prev[jj];
     }
 }
 
 void launch_analysis(const AnalysisArgs &a, hipStream_t s) {
-    dim3 grid(a.Bpad / 16, a.T);
-    size_t lds = 6144 + 4 * kFftBufFloats * 4 + (size_t) a.nbf * 1024;
-    if (a.precision == kBf16)
-        hipLaunchKernelGGL(analysis_kernel<PBF16>, grid, dim3(256), lds, s, a);
-    else
-        hipLaunchKernelGGL(analysis_kernel<PF32>, grid, dim3(256), lds, s, a);
+    dim3 grid(a.Bpad / 16, (a.T + a.seg - 1) / a.seg);
+    const size_t lds = kOffStftEnd + 2 * 272 * 4 + 2 * (size_t) a.nbf * 1024;
+    if (a.precision == kBf16) {
+        if (a.write_spec)
+            hipLaunchKernelGGL((analysis_kernel<PBF16, true>), grid, dim3(256), lds, s, a);
+        else
+            hipLaunchKernelGGL((analysis_kernel<PBF16, false>), grid, dim3(256), lds, s, a);
+    } else {
+        if (a.write_spec)
+            hipLaunchKernelGGL((analysis_kernel<PF32, true>), grid, dim3(256), lds, s, a);
+        else
+            hipLaunchKernelGGL((analysis_kernel<PF32, false>), grid, dim3(256), lds, s, a);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ synthesis
 
-constexpr int kMaskLd = 273;  // row stride (floats) of the row-major mask tile in LDS: odd, so column walks are conflict-free
-
-// 8 waves per workgroup, two streams per wave: the grid is only (streams / 16) x segments workgroups (512 at the bench
-// size, two per CU), so with four waves each a SIMD held two waves and every wave paid its FFT's LDS round trips alone.
-constexpr int kSynWaves = 8, kSynStreams = 16 / kSynWaves;
-
-__global__ __launch_bounds__(64 * kSynWaves) void synthesis_kernel(SynthesisArgs g) {
+// grid (stream tiles, time segments); a workgroup produces frames [t0, t1) of its 16 streams.  A segment that does not
+// start at 0 first replays frame t0 - 1 (no output) to rebuild the overlap-add tail it inherits.
+// kRecompute: the spectrum of a frame is rebuilt from its 512 B of PCM (one more FFT in registers) instead of being read
+// back as 2 KiB of fp32 that the analysis kernel would have had to write: the arithmetic is the analysis kernel's, so
+// the result is the same bit for bit.  The stored form remains for single-frame calls, where the analysis kernel
+// updates the history in place and the previous frame is gone by the time this kernel runs.
+template <bool kRecompute>
+__global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2 *tw = (float2 *) smem;
-    float *win = (float *) (smem + 4096);
-    float *fftbuf = (float *) (smem + 6144);
-    float *mrow = (float *) (smem + 6144 + kSynWaves * kFftBufFloats * 4);  // [16][kMaskLd] fp32
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mt = blockIdx.x;
-    const int mtiles = g.Bpad >> 4;
-    // this workgroup produces frames [t0, t1) of its 16 streams; a segment that does not start at 0 first replays
-    // frame t0 - 1 (no output) to rebuild the overlap-add tail it inherits
+    const int c = fft_column(lane), q = lane >> 4, row = wave * 4 + q;
+    const int mt = blockIdx.x, mtiles = g.Bpad >> 4;
     const int t0 = blockIdx.y * g.seg, t1 = min(g.T, t0 + g.seg);
-    for (int i = tid; i < 512; i += 64 * kSynWaves) {
-        tw[i] = ((const float2 *) g.twiddle)[i];
-        win[i] = g.window[i];
-    }
-    float *buf = fftbuf + wave * kFftBufFloats;
+    const int tb = t0 > 0 ? t0 - 1 : 0;
+    const int b = mt * 16 + row;
+    const bool valid = b < g.B;
     const size_t row_len = (size_t) g.T * kFrame;
+    const int16_t *pcm_row = g.pcm + (size_t) (valid ? b : g.B - 1) * row_len;  // (ragged tile: see analysis_kernel)
 
-    // overlap-add tail of this wave's streams: lane holds samples 2n, 2n+1 for n = lane, lane + 64
-    float2 tl[kSynStreams][2];
-#pragma unroll
-    for (int f = 0; f < kSynStreams; ++f) {
-        const int b = mt * 16 + wave * kSynStreams + f;
-        const float2 *tp = (const float2 *) (g.tail_in + (size_t) b * kFrame);
-        tl[f][0] = tp[lane];
-        tl[f][1] = tp[lane + 64];
+    int prev[8], cur[8], nxt[8];
+    if (kRecompute) {
+        load_frame(prev, tb == 0 ? g.hist_in + (size_t) b * kFrame : pcm_row + (size_t) (tb - 1) * kFrame, c);
+        load_frame(cur, pcm_row + (size_t) tb * kFrame, c);
     }
+    // overlap-add tail of this lane's points n = c + 16 k2, k2 = 8..15 (samples 2n, 2n + 1 of the block's second half)
+    cpx tl[8];
+    {
+        const float2 *tp = (const float2 *) (g.tail_in + (size_t) b * kFrame);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float2 v = tp[c + 16 * j];
+            tl[j] = cpx{v.x, v.y};
+        }
+    }
+    stft_load_tables(smem, g.twiddle, g.window, tid);
+    __syncthreads();
+    char *xw;
+    const char *xr, *twl_c;
+    fft_lane_bases(smem + kOffXbuf + wave * kFftWaveBytes, smem + kOffTwl, lane, &xw, &xr, &twl_c);
+    const char *tw_c = smem + kOffTw + c * 8, *win_c = smem + kOffWin + c * 8;
 
-    // software pipeline: the mask tile of frame t+1 and the spectrum of the next (frame, stream) are requested from HBM
-    // before the current one is transformed; without it every wave sits out one memory latency per frame
-    const int tb = (t0 > 0 ? t0 - 1 : 0);
-    constexpr int kSynThreads = 64 * kSynWaves;
-    constexpr int kMaskVecs = (kMaskTiles * 64 + kSynThreads - 1) / kSynThreads;  // f32x4 per thread per mask tile
-    f32x4 mnext[kMaskVecs];
-    auto mask_fetch = [&](int t) {
-        const f32x4 *src = (const f32x4 *) g.mask + ((size_t) t * mtiles + mt) * kMaskTiles * 64;
+    // mask element (row, k): C-packed tile k / 16, lane (row >> 2) * 16 + (k & 15), value row & 3 -- for a fixed k2 the
+    // wave reads one contiguous 1 KiB tile
+    const unsigned mlane = ((unsigned) (wave * 16 + c) * 4u + (unsigned) q) * 4u;
+    // The mask tile (and, when the spectrum is stored, the spectrum) of the NEXT frame is requested before the current one
+    // is transformed: without it every wave sits out one memory latency per frame.
+    float mk[17], mkn[17];
+    auto mask_fetch = [&](float (&m)[17], int t) {
+        const __amdgpu_buffer_rsrc_t mr = make_rsrc(g.mask + ((size_t) t * mtiles + mt) * kMaskTiles * 256, kMaskTiles * 1024);
 #pragma unroll
-        for (int j = 0; j < kMaskVecs; ++j) {
-            const int i = tid + kSynThreads * j;
-            if (i < kMaskTiles * 64) mnext[j] = src[i];
+        for (int k2 = 0; k2 < 16; ++k2)
+            m[k2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mr, mlane, k2 * 1024u, 0));
+        m[16] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mr, ((unsigned) (wave * 16) * 4u + (unsigned) q) * 4u, 16 * 1024u, 0));
+    };
+    cpx xs[16], xsn[16];
+    auto spec_fetch = [&](cpx (&dst)[16], int t) {
+        const f32x4 *spec = (const f32x4 *) g.spec + ((size_t) t * g.Bpad + b) * 128;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; k2 += 2) {
+            const f32x4 v = spec[(k2 >> 1) * 16 + c];
+            dst[k2] = cpx{v[0], v[1]};
+            dst[k2 + 1] = cpx{v[2], v[3]};
         }
     };
-    // The spectrum of the next (frame, stream) is requested before the current one is transformed.  Two register sets
-    // alternate between the (two) streams of a frame, so the set filled last in a frame is the one read first in the next
-    // and the loop carries no register copies (with a single set hipcc rotated it at the back edge, which needs the data
-    // -- and every store before it in the vector-memory queue -- to have arrived).  Every fetch and store in the loop is
-    // unconditional: past the last frame the fetches re-read the last frame, and frames that must not be written get a
-    // zero-length buffer descriptor; conditional vector-memory operations make hipcc's s_waitcnt placement drain the queue.
-    float2 skA[4], scA[4], skB[4], scB[4];
-    auto spec_fetch = [&](float2 (&sk)[4], float2 (&sc)[4], int t, int f) {
-        const int b = mt * 16 + wave * kSynStreams + f;
-        const float2 *spec = (const float2 *) g.spec + ((size_t) t * g.Bpad + b) * 256;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = lane + 64 * r;
-            sk[r] = spec[k];
-            sc[r] = spec[(256 - k) & 255];
-        }
-    };
-    mask_fetch(tb);
-    spec_fetch(skA, scA, tb, 0);
-    const unsigned lane4 = lane * 4u;
-
-    auto stream = [&](const int t, const int f, const bool emit, float2 (&sk)[4], float2 (&sc)[4], float2 (&nk)[4],
-                      float2 (&nc)[4]) {
-        const int row = wave * kSynStreams + f;
-        const int b = mt * 16 + row;
-        const float *mk_row = mrow + row * kMaskLd;
-        {
-            const int tn = f < kSynStreams - 1 ? t : (t + 1 < t1 ? t + 1 : t);
-            spec_fetch(nk, nc, tn, f < kSynStreams - 1 ? f + 1 : 0);
-        }
-        cpx v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = lane + 64 * r;
-            float2 xk = sk[r], xc = sc[r];
-            float mk = mk_row[k];
-            float mc = mk_row[256 - k];  // mirrored bin (256 when k == 0)
-            cpx yk, yc;
-            if (k == 0) {
-                yk = {mk * xk.x, 0.0f};
-                yc = {mc * xk.y, 0.0f};
-            } else {
-                yk = {mk * xk.x, mk * xk.y};
-                yc = {mc * xc.x, -(mc * xc.y)};
-            }
-            float2 w = tw[k];
-            cpx e = cadd(yk, yc), d = csub(yk, yc);
-            cpx o = cmul(d, cpx{w.x, -w.y});  // conj(W^k) (yk - yc)
-            // Z' = E + i O (both carry the factor 1/2); fed to the forward FFT with re/im swapped = inverse FFT
-            float zr = 0.5f * (e.x - o.y), zi = 0.5f * (e.y + o.x);
-            v[r] = {zi, zr};
-        }
-        fft256_wave(v, buf, tw, lane);
-        int packed[2];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = lane + 64 * r;
-            // swapped output: re <-> im
-            const cpx zz = ((const cpx *) buf)[n];
-            float x0 = zz.y * (1.0f / 256.0f);
-            float x1 = zz.x * (1.0f / 256.0f);
-            float y0 = x0 * win[2 * n], y1 = x1 * win[2 * n + 1];
-            if (r < 2) {
-                float a0 = (tl[f][r].x + y0) * 32768.0f, a1 = (tl[f][r].y + y1) * 32768.0f;
-                a0 = __builtin_fminf(__builtin_fmaxf(__builtin_roundf(a0), -32768.0f), 32767.0f);
-                a1 = __builtin_fminf(__builtin_fmaxf(__builtin_roundf(a1), -32768.0f), 32767.0f);
-                packed[r] = ((int) a0 & 0xffff) | ((int) a1 << 16);
-            } else {
-                tl[f][r - 2] = float2{y0, y1};
-            }
-        }
-        {
-            const bool wr = emit && b < g.B;
-            const __amdgpu_buffer_rsrc_t o =
-                make_rsrc(g.out + (wr ? (size_t) b * row_len + (size_t) t * kFrame : (size_t) 0), wr ? kFrame * 2u : 0u);
-            __builtin_amdgcn_raw_buffer_store_b32(packed[0], o, lane4, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(packed[1], o, lane4 + 256u, 0, 0);
-        }
-        wave_lds_sync();
-    };
+    mask_fetch(mk, tb);
+    if (!kRecompute) spec_fetch(xs, tb);
 
     for (int t = tb; t < t1; ++t) {
         const bool emit = t >= t0;
-        __syncthreads();  // previous frame's readers are done with the mask tile
-        // C-packed fp32 tile [17][64 lanes][4 rows] -> row-major [16][kMaskLd]
+        const int tn = t + 1 < t1 ? t + 1 : t;
+        mask_fetch(mkn, tn);
+        cpx x[16];
+        if (kRecompute) {
+            load_frame(nxt, pcm_row + (size_t) tn * kFrame, c);
+            cpx v[16];
+            window_block(v, prev, cur, win_c);
+            fft256_rows(v, twl_c, xw, xr);
+            real_spectrum(v, x, tw_c, c);
+        } else {
+            spec_fetch(xsn, tn);
 #pragma unroll
-        for (int j = 0; j < kMaskVecs; ++j) {
-            const int i = tid + kSynThreads * j;
-            if (i < kMaskTiles * 64) {
-                const int nt = i >> 6, l = i & 63;
-                const int col = nt * 16 + (l & 15), row = (l >> 4) * 4;
+            for (int k2 = 0; k2 < 16; ++k2) x[k2] = xs[k2];
+        }
+        // Y = mask . X; bin 0 holds DC and Nyquist (both real): its slot travels as {m[0] X[0], m[256] X[256]} and is taken
+        // apart again below
+        cpx y[16];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mrow[(row + r) * kMaskLd + col] = mnext[j][r];
+        for (int k2 = 0; k2 < 16; ++k2) y[k2] = cpx{mk[k2] * x[k2].x, mk[k2] * x[k2].y};
+        cpx yp[16];
+        fft_partner(y, yp, c);
+        cpx v[16];
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            cpx yk = y[k2], yq = yp[k2];  // Y[k], Y[256 - k]
+            if (k2 == 0 && c == 0) {
+                yk = cpx{mk[0] * x[0].x, 0.0f};
+                yq = cpx{mk[16] * x[0].y, 0.0f};
+            }
+            const float2 w = *(const float2 *) (tw_c + k2 * 128);
+            // e = Y[k] + conj(Y[256 - k]), d = Y[k] - conj(Y[256 - k]), o = conj(W^k) d
+            const cpx e = {yk.x + yq.x, yk.y - yq.y}, d = {yk.x - yq.x, yk.y + yq.y};
+            const cpx o = cmul(d, cpx{w.x, -w.y});
+            // Z' = E + i O (both carry the factor 1/2); fed to the forward FFT with re/im swapped = inverse FFT
+            const float zr = 0.5f * (e.x - o.y), zi = 0.5f * (e.y + o.x);
+            v[k2] = cpx{zi, zr};
+        }
+        fft256_rows(v, twl_c, xw, xr);
+        int packed[8];
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const float2 w = *(const float2 *) (win_c + k2 * 128);  // window[2n], window[2n + 1], n = c + 16 k2
+            // swapped output: re <-> im
+            const float x0 = v[k2].y * (1.0f / 256.0f), x1 = v[k2].x * (1.0f / 256.0f);
+            const float y0 = x0 * w.x, y1 = x1 * w.y;
+            if (k2 < 8) {
+                float a0 = (tl[k2].x + y0) * 32768.0f, a1 = (tl[k2].y + y1) * 32768.0f;
+                a0 = __builtin_fminf(__builtin_fmaxf(__builtin_roundf(a0), -32768.0f), 32767.0f);
+                a1 = __builtin_fminf(__builtin_fmaxf(__builtin_roundf(a1), -32768.0f), 32767.0f);
+                packed[k2] = ((int) a0 & 0xffff) | ((int) a1 << 16);
+            } else {
+                v[k2] = cpx{y0, y1};
             }
         }
-        mask_fetch(t + 1 < t1 ? t + 1 : t);
-        __syncthreads();
-        static_assert(kSynStreams == 2, "the two prefetch sets alternate over an even number of streams");
-        stream(t, 0, emit, skA, scA, skB, scB);
-        stream(t, 1, emit, skB, scB, skA, scA);
+#pragma unroll
+        for (int k2 = 8; k2 < 16; ++k2) tl[k2 - 8] = v[k2];
+        {
+            // one wave-uniform descriptor over the wave's four stream rows of this frame (a per-lane base would make hipcc
+            // wrap every store in a loop over the distinct descriptors); rows that must not be written -- the replayed
+            // frame, streams past the last one -- fall outside the descriptor's range and are dropped by the hardware
+            const int row0 = mt * 16 + wave * 4;
+            const int rows_ok = row0 < g.B ? min(4, g.B - row0) : 0;
+            const unsigned span = emit && rows_ok ? (unsigned) ((size_t) (rows_ok - 1) * row_len * 2 + kFrame * 2) : 0u;
+            const __amdgpu_buffer_rsrc_t o = make_rsrc(g.out + (size_t) row0 * row_len + (size_t) t * kFrame, span);
+            const unsigned voff = (unsigned) q * (unsigned) (row_len * 2) + (unsigned) c * 4u;
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) __builtin_amdgcn_raw_buffer_store_b32(packed[k2], o, voff, 64u * k2, 0);
+        }
+        if (kRecompute) {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                prev[jj] = cur[jj];
+                cur[jj] = nxt[jj];
+            }
+        } else {
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) xs[k2] = xsn[k2];
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 17; ++k2) mk[k2] = mkn[k2];
     }
     if (t1 == g.T) {
+        float2 *tp = (float2 *) (g.tail_out + (size_t) b * kFrame);
 #pragma unroll
-        for (int f = 0; f < kSynStreams; ++f) {
-            const int b = mt * 16 + wave * kSynStreams + f;
-            float2 *tp = (float2 *) (g.tail_out + (size_t) b * kFrame);
-            tp[lane] = tl[f][0];
-            tp[lane + 64] = tl[f][1];
-        }
+        for (int j = 0; j < 8; ++j) tp[c + 16 * j] = float2{tl[j].x, tl[j].y};
     }
 }
 
 void launch_synthesis(const SynthesisArgs &a, hipStream_t s) {
-    size_t lds = 6144 + kSynWaves * kFftBufFloats * 4 + 16 * kMaskLd * 4;
-    hipLaunchKernelGGL(synthesis_kernel, dim3(a.Bpad / 16, (a.T + a.seg - 1) / a.seg), dim3(64 * kSynWaves), lds, s, a);
+    const size_t lds = kOffStftEnd;
+    const dim3 grid(a.Bpad / 16, (a.T + a.seg - 1) / a.seg);
+    if (a.recompute)
+        hipLaunchKernelGGL(synthesis_kernel<true>, grid, dim3(256), lds, s, a);
+    else
+        hipLaunchKernelGGL(synthesis_kernel<false>, grid, dim3(256), lds, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------ reset

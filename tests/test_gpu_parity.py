@@ -26,7 +26,9 @@ def lsb(a, b):
 
 
 @pytest.mark.parametrize('B,T,calls', [(1, 1, 4), (19, 3, 2), (40, 8, 1), (16, 1, 3)])
-def test_fp32_stage_taps_and_pcm(random_model, B, T, calls):
+def test_fp32_stage_taps_and_pcm(random_model, monkeypatch, B, T, calls):
+    # (multi-frame calls do not store the spectrum at all -- the synthesis kernel rebuilds it -- unless the taps are on)
+    monkeypatch.setenv('KOALA_AMD_DEBUG_TAPS', '1')
     x = synth_streams(B, T * calls, seed=100 + B)
     kb = koala_amd.create_batch('key', B, T, 'fp32', model_path=random_model)
     streams = [oracle.Oracle(random_model) for _ in range(B)]
@@ -275,7 +277,8 @@ def test_alternative_kernels_give_identical_pcm(random_model):
     script = _SWITCH_SCRIPT % {'root': root, 'tests': os.path.join(root, 'tests'), 'model': random_model}
     digests = {}
     for switch in ('', 'KOALA_AMD_GRU_STREAM', 'KOALA_AMD_GEMM_GENERIC', 'KOALA_AMD_GEMM_WS1',
-                   'KOALA_AMD_GEMM_NO_WSR', 'KOALA_AMD_NO_SMALL', 'KOALA_AMD_NO_GRAPH'):
+                   'KOALA_AMD_GEMM_NO_WSR', 'KOALA_AMD_NO_SMALL', 'KOALA_AMD_NO_GRAPH', 'KOALA_AMD_STORE_SPECTRUM',
+                   'KOALA_AMD_DEBUG_TAPS'):
         env = dict(os.environ)
         if switch:
             env[switch] = '1'
