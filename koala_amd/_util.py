@@ -12,7 +12,8 @@ def default_library_path(relative: str = '') -> str:
 
 
 def default_model_path(relative: str = '') -> str:
-    """The default parameter file written by `build_native()` (hand-built spectral-gate set, see params.py)."""
+    """The default parameter file written by `build_native()`: the hand-built spectral gate with an adaptive noise floor
+    (params.make_adaptive_gate) -- nothing in it is derived from an audio file."""
     return os.path.join(_PKG, relative, 'lib', 'koala_params.kns')
 
 
@@ -42,9 +43,12 @@ def build_native(force: bool = False) -> str:
             finally:
                 fcntl.flock(lock, fcntl.LOCK_UN)
     model = default_model_path()
-    if not os.path.exists(model):
+    tag, kind = model + '.kind', 'adaptive-gate-v1'
+    if not os.path.exists(model) or not os.path.exists(tag) or open(tag).read().strip() != kind:
         from . import params
-        params.write_params(model, params.make_gate())
+        params.write_params(model, params.make_adaptive_gate())
+        with open(tag, 'w') as f:
+            f.write(kind + '\n')
     return lib
 
 

@@ -162,7 +162,9 @@ struct PBF16 {
 
 // ------------------------------------------------------------------------------------------------ FFT-256 per wave
 
-// complex numbers as packed pairs: add/sub are one v_pk_add_f32, a complex multiply is v_pk_mul_f32 + v_pk_fma_f32
+// complex numbers
+#ifdef KNS_CPX_PACKED
+// as packed pairs: add/sub are one v_pk_add_f32, a complex multiply is v_pk_mul_f32 + v_pk_fma_f32
 typedef float cpx __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ cpx cadd(cpx a, cpx b) { return a + b; }
 __device__ __forceinline__ cpx csub(cpx a, cpx b) { return a - b; }
@@ -170,6 +172,18 @@ __device__ __forceinline__ cpx cmul(cpx a, cpx w) {
     const cpx t = cpx{a.y, a.y} * cpx{-w.y, w.x};
     return __builtin_elementwise_fma(cpx{a.x, a.x}, w, t);
 }
+#else
+// as two scalars (the same operations as the packed form, one lane-operation each: on gfx950 a packed f32 instruction
+// takes the issue time of two plain ones, and its operands must sit in aligned register pairs, which costs moves)
+struct alignas(8) cpx {
+    float x, y;
+};
+__device__ __forceinline__ cpx cadd(cpx a, cpx b) { return cpx{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cpx csub(cpx a, cpx b) { return cpx{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cpx cmul(cpx a, cpx w) {
+    return cpx{__builtin_fmaf(a.x, w.x, a.y * -w.y), __builtin_fmaf(a.x, w.y, a.y * w.x)};
+}
+#endif
 
 __device__ __forceinline__ void radix4(cpx (&v)[4]) {
     cpx a0 = cadd(v[0], v[2]), a1 = csub(v[0], v[2]), a2 = cadd(v[1], v[3]), d = csub(v[1], v[3]);

@@ -59,6 +59,13 @@ def random_model():
 
 @pytest.fixture(scope='session')
 def gate_model():
+    """The default model: the hand-built spectral gate with an adaptive noise floor (nothing derived from an audio file)."""
+    return model_file('adaptive')
+
+
+@pytest.fixture(scope='session')
+def prior_gate_model():
+    """Round 1's gate, whose fixed threshold is the mean spectrum of the reference's noise fixture (kept for comparison)."""
     return model_file('gate')
 
 

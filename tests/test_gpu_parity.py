@@ -232,7 +232,7 @@ def test_ragged_large_batches_take_the_fallback_kernels(random_model, precision,
     assert lsb(got, ref).max() <= (6 if precision == 'bf16' else 1)
 
 
-@pytest.mark.parametrize('kind', ['random', 'gate'])
+@pytest.mark.parametrize('kind', ['random', 'gate', 'adaptive'])
 def test_against_committed_golden_vectors(kind):
     """The engine against tests/golden/kns_v1_golden.npz (written by tools/make_golden.py from the oracle): no oracle
     run involved."""

@@ -44,16 +44,22 @@ def test_delay_sample(koala):
     assert koala.delay_sample >= 0
 
 
-def test_pure_speech(gate_model, test_pcm):
-    _run_test(gate_model, test_pcm, test_pcm)
+@pytest.fixture(params=['adaptive', 'prior'])
+def envelope_model(request, gate_model, prior_gate_model):
+    """the default model (adaptive noise floor, nothing derived from an audio file) and round 1's fixture-calibrated gate"""
+    return gate_model if request.param == 'adaptive' else prior_gate_model
 
 
-def test_pure_noise(gate_model, noise_pcm):
-    _run_test(gate_model, noise_pcm)
+def test_pure_speech(envelope_model, test_pcm):
+    _run_test(envelope_model, test_pcm, test_pcm)
 
 
-def test_mixed(gate_model, test_pcm, noise_pcm):
-    _run_test(gate_model, [int(a) + int(b) for a, b in zip(test_pcm, noise_pcm)], test_pcm)
+def test_pure_noise(envelope_model, noise_pcm):
+    _run_test(envelope_model, noise_pcm)
+
+
+def test_mixed(envelope_model, test_pcm, noise_pcm):
+    _run_test(envelope_model, [int(a) + int(b) for a, b in zip(test_pcm, noise_pcm)], test_pcm)
 
 
 def test_reset(koala, test_pcm):

@@ -42,6 +42,13 @@ def test_wav_fixture_metadata(test_pcm, noise_pcm):
     assert mixed.max() == 13145 and mixed.min() == -11437
 
 
+@pytest.fixture(params=['adaptive', 'prior'])
+def gate_model(request, prior_gate_model):
+    """the envelope tests run on the default (adaptive-floor) model and on round 1's fixture-calibrated gate"""
+    from conftest import model_file
+    return model_file('adaptive') if request.param == 'adaptive' else prior_gate_model
+
+
 def test_pure_speech_envelope(gate_model, test_pcm):
     o = oracle.Oracle(gate_model)
     dev = envelope(lambda f: o.process(f), test_pcm, test_pcm)
@@ -157,10 +164,11 @@ def test_stage_entry_points_agree_with_full_path(random_model, test_pcm):
     assert y.dtype == np.int16 and tail.any()
 
 
-def test_oracle_reproduces_committed_golden_vectors(random_model, gate_model):
+def test_oracle_reproduces_committed_golden_vectors(random_model, prior_gate_model):
     """tests/golden/kns_v1_golden.npz (tools/make_golden.py): the spec pinned as data."""
     g = np.load(os.path.join(GOLDEN, 'kns_v1_golden.npz'))
-    for kind, model in (('random', random_model), ('gate', gate_model)):
+    from conftest import model_file
+    for kind, model in (('random', random_model), ('gate', prior_gate_model), ('adaptive', model_file('adaptive'))):
         for prec, name in ((oracle.PREC_FP32, 'fp32'), (oracle.PREC_BF16, 'bf16')):
             got = oracle.Oracle(model, 3, prec).process(g['pcm'])
             want = g['%s_%s' % (kind, name)]

@@ -1,6 +1,6 @@
 """
 Writes tests/golden/kns_v1_golden.npz: input frames and the oracle's int16 output for them, for the seeded-random and
-the gate parameter sets in both precision modes.  The vectors pin the KNS-v1 spec itself (oracle regressions, compiler
+the two gate parameter sets (fixture-calibrated `gate`, adaptive-floor `adaptive`) in both precision modes.  The vectors pin the KNS-v1 spec itself (oracle regressions, compiler
 or libm drift on another host) and give the GPU parity tests a committed target that does not depend on running the
 oracle.  Inputs: 48 frames of resources/audio_samples/test.wav starting at the first speech onset, the same span of
 noise.wav, and their sum.
@@ -22,7 +22,7 @@ def main():
     a, n = 34 * 256, 48 * 256
     x = np.stack([test[a:a + n], noise[a:a + n], (test[a:a + n].astype(np.int32) + noise[a:a + n]).astype(np.int16)])
     out = {'pcm': x}
-    for kind in ('random', 'gate'):
+    for kind in ('random', 'gate', 'adaptive'):
         model = model_file(kind)
         for prec, name in ((oracle.PREC_FP32, 'fp32'), (oracle.PREC_BF16, 'bf16')):
             out['%s_%s' % (kind, name)] = oracle.Oracle(model, 3, prec).process(x)
