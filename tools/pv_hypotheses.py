@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""
+BUILD-CONTAINER ONLY (reads /root/reference/lib/common/koala_params.pv; nothing of it is copied into the repository).
+
+Scores import hypotheses for the reference's model file (koala_amd.pv_import.Hypothesis: weight / bias shifts, gate
+order, stage-input row order, feature-table formats, which of the front-end's five context frames a one-frame front-end
+keeps) by the one behavioural contract the reference publishes: the acceptance envelope of
+binding/python/test_koala.py:71-114 on test.wav, noise.wav and their mix, evaluated with the CPU oracle.
+Writes profiles/r02_pv_import_search.json: how many hypotheses were tried, the distribution of the scores and the best
+ones with all three deviations.  A score below 0.02 would mean "this reading of the bytes behaves like a noise suppressor
+on the reference's own fixtures"; whatever comes out is recorded as measured.
+"""
+import itertools
+import json
+import multiprocessing as mp
+import os
+import random
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+PV = '/root/reference/lib/common/koala_params.pv'
+
+SPACE = dict(weight_shift=[5, 6, 7, 8, 9], bias_shift=[3, 4, 5, 6, 7], front_shift=[5, 6, 7, 8, 9], front_bias_shift=[3, 4, 5, 6, 7],
+             front_tap=[-1, 0, 1, 2, 3, 4], mean_div=[256.0, 512.0, 1024.0], scale_div=[2048.0, 4096.0, 8192.0],
+             log2_features=[False, True], gate_order=[''.join(p) for p in itertools.permutations('rzn')], y_first=[True, False],
+             head_shift=[5, 6, 7, 8], head_bias_shift=[3, 4, 5, 6])
+
+
+def rms(x):
+    return np.sqrt(np.mean((x.astype(np.float64) / 32768.0) ** 2, axis=-1))
+
+
+def evaluate(h):
+    os.environ['OMP_NUM_THREADS'] = '1'
+    from conftest import load_wav
+    from koala_amd import params, pv_import
+    from oracle import oracle
+    model = pv_import.read_pv(PV)
+    test, noise = load_wav('test.wav'), load_wav('noise.wav')
+    n = len(test) // 256 * 256
+    x = np.stack([test[:n], noise[:n], (test[:n].astype(int) + noise[:n]).astype(np.int16)])
+    path = os.path.join(tempfile.gettempdir(), 'pvh_%d.kns' % os.getpid())
+    params.write_params(path, pv_import.to_kns1(model, pv_import.Hypothesis(**h)))
+    y = oracle.Oracle(path, 3).process(x, num_threads=1)
+    fo, fi = rms(y.reshape(3, -1, 256)), rms(x.reshape(3, -1, 256))
+    ref = fi[0]
+    dev = {'speech': float(np.abs(fo[0][1:] - ref[:-1]).max()), 'noise': float(fo[1].max()),
+           'mixed': float(np.abs(fo[2][1:] - ref[:-1]).max())}
+    # two scale-free descriptors: how much of the noise survives, how much of the active speech survives
+    act = ref[:-1] > 0.03
+    dev['noise_gain_db'] = float(20 * np.log10(max(rms(y[1][8000:]), 1e-9) / rms(noise[8000:n])))
+    dev['speech_gain_db'] = float(20 * np.log10(max(np.median(fo[0][1:][act] / ref[:-1][act]), 1e-9)))
+    return h, dev
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1600
+    rnd = random.Random(20260928)
+    hyps = [dict()]  # the default reading first
+    while len(hyps) < n:
+        hyps.append({k: rnd.choice(v) for k, v in SPACE.items()})
+    with mp.Pool(min(8, os.cpu_count() or 1)) as pool:
+        results = pool.map(evaluate, hyps, chunksize=8)
+    scored = sorted(results, key=lambda r: max(r[1]['speech'], r[1]['noise'], r[1]['mixed']))
+    scores = np.array([max(r[1]['speech'], r[1]['noise'], r[1]['mixed']) for r in scored])
+    # "behaves like a suppressor": removes >= 6 dB of the noise while keeping speech within 3 dB
+    useful = [r for r in results if r[1]['noise_gain_db'] <= -6.0 and abs(r[1]['speech_gain_db']) <= 3.0]
+    out = {
+        'tool': 'tools/pv_hypotheses.py', 'hypotheses_tried': len(results), 'space': {k: [str(x) for x in v] for k, v in SPACE.items()},
+        'score': 'max over {pure speech, pure noise, mixed} of the per-frame RMS deviation of the reference test (pass < 0.02)',
+        'score_quantiles': {q: float(np.quantile(scores, float(q))) for q in ('0.0', '0.01', '0.1', '0.5', '0.9')},
+        'passing': int((scores < 0.02).sum()),
+        'suppressor_like': len(useful),
+        'default_hypothesis': {'hypothesis': results[0][0], 'metrics': results[0][1]},
+        'best': [{'hypothesis': h, 'metrics': d} for h, d in scored[:10]],
+        'best_suppressor_like': [{'hypothesis': h, 'metrics': d} for h, d in sorted(useful, key=lambda r: r[1]['noise_gain_db'])[:5]],
+    }
+    path = os.path.join(ROOT, 'profiles', 'r02_pv_import_search.json')
+    json.dump(out, open(path, 'w'), indent=1)
+    print(json.dumps({k: out[k] for k in ('hypotheses_tried', 'score_quantiles', 'passing', 'suppressor_like')}, indent=1))
+    for e in out['best'][:3]:
+        print(e)
+
+
+if __name__ == '__main__':
+    main()
