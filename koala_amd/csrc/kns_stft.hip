@@ -11,17 +11,21 @@ namespace kns {
 // 256-point complex sequence is live: packed samples z[n] = x[2n] + i x[2n+1], FFT bins, inverse-FFT input.  Every table
 // the lane needs is indexed by such n, so it sits in LDS in natural order and is read at (lane base + immediate offset).
 constexpr int kOffTw = 0;                               // float2[512]: exp(-2 pi i k / 512)
-constexpr int kOffWin = 4096;                           // float[512]:  sin(pi n / 512)
-constexpr int kOffTwl = kOffWin + 2048;                 // fft_fill_twiddles table
+constexpr int kOffWin = 4096;                           // float[512]:  sin(pi n / 512) / 32768 (analysis: int16 -> windowed sample)
+constexpr int kOffWinS = kOffWin + 2048;                // float[512]:  sin(pi n / 512) / 256   (synthesis: FFT sum -> windowed sample)
+constexpr int kOffTwl = kOffWinS + 2048;                // fft_fill_twiddles table
 constexpr int kOffXbuf = kOffTwl + kFftTwiddleBytes;    // 4 waves x kFftWaveBytes
 constexpr int kOffStftEnd = kOffXbuf + 4 * kFftWaveBytes;
 
 __device__ __forceinline__ void stft_load_tables(char *smem, const float *twiddle, const float *window, int tid) {
     float2 *tw = (float2 *) (smem + kOffTw);
-    float *win = (float *) (smem + kOffWin);
+    float *win = (float *) (smem + kOffWin), *wins = (float *) (smem + kOffWinS);
     for (int i = tid; i < 512; i += 256) {
         tw[i] = ((const float2 *) twiddle)[i];
-        win[i] = window[i];
+        // the powers of two of the spec's (x / 32768) w and (y / 256) w are folded into the window: exact, so the
+        // products are the spec's bit for bit
+        win[i] = window[i] * (1.0f / 32768.0f);
+        wins[i] = window[i] * (1.0f / 256.0f);
     }
     fft_fill_twiddles(smem + kOffTwl, (const float2 *) twiddle, tid, 256);
 }
@@ -39,8 +43,8 @@ __device__ __forceinline__ void window_block(cpx (&v)[16], const int (&prev)[8],
         const int pr = j < 8 ? prev[j] : cur[j - 8];
         const float2 w = *(const float2 *) (win_c + j * 128);  // window[2n], window[2n + 1], n = 16 j + c
         const float lo = (float) (int16_t) (pr & 0xffff), hi = (float) (int16_t) (pr >> 16);
-        v[j].x = (lo * (1.0f / 32768.0f)) * w.x;
-        v[j].y = (hi * (1.0f / 32768.0f)) * w.y;
+        v[j].x = lo * w.x;  // = (lo / 32768) window[2n]: the window table carries the 2^-15
+        v[j].y = hi * w.y;
     }
 }
 
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
     char *xw;
     const char *xr, *twl_c;
     fft_lane_bases(smem + kOffXbuf + wave * kFftWaveBytes, smem + kOffTwl, lane, &xw, &xr, &twl_c);
-    const char *tw_c = smem + kOffTw + c * 8, *win_c = smem + kOffWin + c * 8;
+    const char *tw_c = smem + kOffTw + c * 8, *win_c = smem + kOffWin + c * 8, *wins_c = smem + kOffWinS + c * 8;
 
     // mask element (row, k): C-packed tile k / 16, lane (row >> 2) * 16 + (k & 15), value row & 3 -- for a fixed k2 the
     // wave reads one contiguous 1 KiB tile
@@ -288,10 +292,9 @@ __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
         int packed[8];
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) {
-            const float2 w = *(const float2 *) (win_c + k2 * 128);  // window[2n], window[2n + 1], n = c + 16 k2
-            // swapped output: re <-> im
-            const float x0 = v[k2].y * (1.0f / 256.0f), x1 = v[k2].x * (1.0f / 256.0f);
-            const float y0 = x0 * w.x, y1 = x1 * w.y;
+            const float2 w = *(const float2 *) (wins_c + k2 * 128);  // window[2n] / 256, window[2n + 1] / 256, n = c + 16 k2
+            // swapped output: re <-> im; = (v / 256) window: the table carries the 2^-8
+            const float y0 = v[k2].y * w.x, y1 = v[k2].x * w.y;
             if (k2 < 8) {
                 float a0 = (tl[k2].x + y0) * 32768.0f, a1 = (tl[k2].y + y1) * 32768.0f;
                 a0 = __builtin_fminf(__builtin_fmaxf(__builtin_roundf(a0), -32768.0f), 32767.0f);

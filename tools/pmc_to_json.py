@@ -11,7 +11,7 @@ CLASS = {'analysis_kernel': 'analysis', 'gemm_ws2_kernel<0, 4>': 'gemm_input', '
          'synthesis_kernel': 'synthesis', 'gemm_wsr_kernel<2, 2>': 'gemm_head'}
 
 
-def main(pmc_dir, out):
+def main(pmc_dir, out, commit=None):
     d = collections.defaultdict(dict)
     for i in range(1, 9):
         try:
@@ -43,11 +43,13 @@ def main(pmc_dir, out):
                             'dtype': json.loads(line)['dtype']}
     except Exception:
         pass
+    if commit:
+        res['_commit'] = commit  # source revision the counters were collected on (bench.py reports it as traffic_commit)
     json.dump(res, open(out, 'w'), indent=1, sort_keys=True)
     for k, v in res.items():
-        if 'class' in v:
+        if isinstance(v, dict) and 'class' in v:
             print(v['class'], v.get('hbm_bytes'))
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
