@@ -187,8 +187,10 @@ void launch_analysis(const AnalysisArgs &a, hipStream_t s) {
 // back as 2 KiB of fp32 that the analysis kernel would have had to write: the arithmetic is the analysis kernel's, so
 // the result is the same bit for bit.  The stored form remains for single-frame calls, where the analysis kernel
 // updates the history in place and the previous frame is gone by the time this kernel runs.
+// (three waves per SIMD: the kernel is bound by VALU issue, and two waves on a SIMD reach an instruction every ~2.8 cycles,
+// three come close to the pipe's 2; the register budget of 168 is what decides which loads are prefetched below)
 template <bool kRecompute>
-__global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
+__global__ __launch_bounds__(256, 3) void synthesis_kernel(SynthesisArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -226,8 +228,6 @@ __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
     // mask element (row, k): C-packed tile k / 16, lane (row >> 2) * 16 + (k & 15), value row & 3 -- for a fixed k2 the
     // wave reads one contiguous 1 KiB tile
     const unsigned mlane = ((unsigned) (wave * 16 + c) * 4u + (unsigned) q) * 4u;
-    // The mask tile (and, when the spectrum is stored, the spectrum) of the NEXT frame is requested before the current one
-    // is transformed: without it every wave sits out one memory latency per frame.
     float mk[17], mkn[17];
     auto mask_fetch = [&](float (&m)[17], int t) {
         const __amdgpu_buffer_rsrc_t mr = make_rsrc(g.mask + ((size_t) t * mtiles + mt) * kMaskTiles * 256, kMaskTiles * 1024);
@@ -246,13 +246,20 @@ __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
             dst[k2 + 1] = cpx{v[2], v[3]};
         }
     };
-    mask_fetch(mk, tb);
-    if (!kRecompute) spec_fetch(xs, tb);
+    if (!kRecompute) {
+        mask_fetch(mk, tb);
+        spec_fetch(xs, tb);
+    }
 
     for (int t = tb; t < t1; ++t) {
         const bool emit = t >= t0;
         const int tn = t + 1 < t1 ? t + 1 : t;
-        mask_fetch(mkn, tn);
+        // recompute: the mask is not needed before the first FFT and the spectrum are through (~700 instructions), so it is
+        // requested here without a second register set; stored spectrum: mask and spectrum of the next frame in flight
+        if (kRecompute)
+            mask_fetch(mk, t);
+        else
+            mask_fetch(mkn, tn);
         cpx x[16];
         if (kRecompute) {
             load_frame(nxt, pcm_row + (size_t) tn * kFrame, c);
@@ -328,8 +335,10 @@ __global__ __launch_bounds__(256) void synthesis_kernel(SynthesisArgs g) {
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) xs[k2] = xsn[k2];
         }
+        if (!kRecompute) {
 #pragma unroll
-        for (int k2 = 0; k2 < 17; ++k2) mk[k2] = mkn[k2];
+            for (int k2 = 0; k2 < 17; ++k2) mk[k2] = mkn[k2];
+        }
     }
     if (t1 == g.T) {
         float2 *tp = (float2 *) (g.tail_out + (size_t) b * kFrame);

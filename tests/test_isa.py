@@ -19,8 +19,12 @@ HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
 def test_no_store_data_hazard_and_no_spills(src, tmp_path):
     import isa_scan
     out = tmp_path / (src + '.s')
-    subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-S', '--cuda-device-only',
-                           '-x', 'hip', os.path.join(ROOT, 'koala_amd', 'csrc', src), '-o', str(out)],
+    # the per-file flags of koala_amd/Makefile (FLAGS_<stem> = ...)
+    mk = open(os.path.join(ROOT, 'koala_amd', 'Makefile')).read()
+    m = re.search(r'^FLAGS_%s\s*=\s*(.*)$' % src.split('.')[0], mk, re.M)
+    extra = m.group(1).split() if m else []
+    subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off'] + extra +
+                          ['-S', '--cuda-device-only', '-x', 'hip', os.path.join(ROOT, 'koala_amd', 'csrc', src), '-o', str(out)],
                           stderr=subprocess.DEVNULL)
     text = out.read_text()
     assert isa_scan.scan(text) == []
