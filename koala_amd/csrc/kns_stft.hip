@@ -17,6 +17,9 @@ constexpr int kOffTwl = kOffWinS + 2048;                // fft_fill_twiddles tab
 constexpr int kOffXbuf = kOffTwl + kFftTwiddleBytes;    // 4 waves x kFftWaveBytes
 constexpr int kOffStftEnd = kOffXbuf + 4 * kFftWaveBytes;
 
+// kSynth: also the synthesis window.  (The analysis kernel leaves that table out and puts its exchange tiles there: 2 KiB
+// decide whether three of its workgroups fit a CU's 160 KiB.)
+template <bool kSynth>
 __device__ __forceinline__ void stft_load_tables(char *smem, const float *twiddle, const float *window, int tid) {
     float2 *tw = (float2 *) (smem + kOffTw);
     float *win = (float *) (smem + kOffWin), *wins = (float *) (smem + kOffWinS);
@@ -25,10 +28,12 @@ __device__ __forceinline__ void stft_load_tables(char *smem, const float *twiddl
         // the powers of two of the spec's (x / 32768) w and (y / 256) w are folded into the window: exact, so the
         // products are the spec's bit for bit
         win[i] = window[i] * (1.0f / 32768.0f);
-        wins[i] = window[i] * (1.0f / 256.0f);
+        if (kSynth) wins[i] = window[i] * (1.0f / 256.0f);
     }
-    fft_fill_twiddles(smem + kOffTwl, (const float2 *) twiddle, tid, 256);
+    fft_fill_twiddles(smem + (kSynth ? kOffTwl : kOffWinS), (const float2 *) twiddle, tid, 256);
 }
+// analysis kernel: [tw | win | fft twiddles | exchange tiles | mean, scale | feature tile]
+constexpr int kOffATwl = kOffWinS, kOffAXbuf = kOffATwl + kFftTwiddleBytes, kOffAEnd = kOffAXbuf + 4 * kFftWaveBytes;
 
 // the eight dwords (sample pairs) this lane owns of one 256-sample frame: pairs 16 jj + c
 __device__ __forceinline__ void load_frame(int (&f)[8], const int16_t *frame, int c) {
@@ -80,11 +85,10 @@ __device__ __forceinline__ float feature_log(float x) {
 // grid (stream tiles, time segments): a workgroup walks the frames [t0, t1) of its 16 streams, so every PCM sample is
 // read once (the previous frame stays in registers) and the per-lane constants are set up once per segment.
 template <class P, bool kSpec>
-__global__ __launch_bounds__(256) void analysis_kernel(AnalysisArgs g) {
+__global__ __launch_bounds__(256, 3) void analysis_kernel(AnalysisArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *lmean = (float *) (smem + kOffStftEnd), *lscale = lmean + 272;
-    typename P::elem_t *tile0 = (typename P::elem_t *) (smem + kOffStftEnd + 2 * 272 * 4);  // 2 x nbf KiB
-    const int tile_elems = g.nbf * 64 * P::EPL;
+    float *lmean = (float *) (smem + kOffAEnd), *lscale = lmean + 272;
+    typename P::elem_t *tile = (typename P::elem_t *) (smem + kOffAEnd + 2 * 272 * 4);  // nbf KiB
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = fft_column(lane), q = lane >> 4, row = wave * 4 + q;
@@ -99,19 +103,19 @@ __global__ __launch_bounds__(256) void analysis_kernel(AnalysisArgs g) {
     int prev[8], cur[8], nxt[8];
     load_frame(prev, t0 == 0 ? g.hist_in + (size_t) b * kFrame : pcm_row + (size_t) (t0 - 1) * kFrame, c);
     load_frame(cur, pcm_row + (size_t) t0 * kFrame, c);
-    stft_load_tables(smem, g.twiddle, g.window, tid);
+    stft_load_tables<false>(smem, g.twiddle, g.window, tid);
     for (int i = tid; i < kBins; i += 256) {
         lmean[i] = g.mean[i];
         lscale[i] = g.scale[i];
     }
     {
-        uint4 *z = (uint4 *) tile0;
-        for (int i = tid; i < 2 * g.nbf * 64; i += 256) z[i] = uint4{0, 0, 0, 0};
+        uint4 *z = (uint4 *) tile;
+        for (int i = tid; i < g.nbf * 64; i += 256) z[i] = uint4{0, 0, 0, 0};
     }
     __syncthreads();
     char *xw;
     const char *xr, *twl_c;
-    fft_lane_bases(smem + kOffXbuf + wave * kFftWaveBytes, smem + kOffTwl, lane, &xw, &xr, &twl_c);
+    fft_lane_bases(smem + kOffAXbuf + wave * kFftWaveBytes, smem + kOffATwl, lane, &xw, &xr, &twl_c);
     const char *tw_c = smem + kOffTw + c * 8, *win_c = smem + kOffWin + c * 8;
     const float *mean_c = lmean + c, *scale_c = lscale + c;
 
@@ -123,7 +127,6 @@ __global__ __launch_bounds__(256) void analysis_kernel(AnalysisArgs g) {
         fft256_rows(v, twl_c, xw, xr);
         cpx x[16];
         real_spectrum(v, x, tw_c, c);
-        typename P::elem_t *tile = tile0 + (t & 1) * tile_elems;
         if (kSpec) {
             // stored in the lane order of this kernel pair: bins (c + 16 k2, c + 16 (k2 + 1)), k2 even, as one 16-byte word
             // at [(k2 / 2) * 16 + c] -- a row of lanes moves 256 contiguous bytes per instruction
@@ -144,12 +147,13 @@ __global__ __launch_bounds__(256) void analysis_kernel(AnalysisArgs g) {
             const float fn = (feature_log<P>(nyq * nyq + 1e-10f) - lmean[256]) * lscale[256];
             tile[(256 / P::KB) * 64 * P::EPL + P::off(row, 256 % P::KB)] = P::cvt(fn);
         }
-        __syncthreads();  // (one barrier per frame: the two tiles alternate)
+        __syncthreads();
         {
             const uint4 *src = (const uint4 *) tile;
             uint4 *dst = (uint4 *) g.feat + ((size_t) t * mtiles + mt) * g.nbf * 64;
             for (int i = tid; i < g.nbf * 64; i += 256) dst[i] = src[i];
         }
+        __syncthreads();  // (a single tile and two barriers per frame: a second tile would cost the third workgroup per CU)
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             prev[jj] = cur[jj];
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(256) void analysis_kernel(AnalysisArgs g) {
 
 void launch_analysis(const AnalysisArgs &a, hipStream_t s) {
     dim3 grid(a.Bpad / 16, (a.T + a.seg - 1) / a.seg);
-    const size_t lds = kOffStftEnd + 2 * 272 * 4 + 2 * (size_t) a.nbf * 1024;
+    const size_t lds = kOffAEnd + 2 * 272 * 4 + (size_t) a.nbf * 1024;
     if (a.precision == kBf16) {
         if (a.write_spec)
             hipLaunchKernelGGL((analysis_kernel<PBF16, true>), grid, dim3(256), lds, s, a);
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(256, 3) void synthesis_kernel(SynthesisArgs g) {
             tl[j] = cpx{v.x, v.y};
         }
     }
-    stft_load_tables(smem, g.twiddle, g.window, tid);
+    stft_load_tables<true>(smem, g.twiddle, g.window, tid);
     __syncthreads();
     char *xw;
     const char *xr, *twl_c;
