@@ -303,6 +303,14 @@ constexpr int kGruTilesPerWave = 5;  // 17 unit tiles over 4 waves: 5,4,4,4
 __device__ __forceinline__ float fast_sigmoid(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
 }
+// sigmoid of the heads: the spec's polynomial form in the fp32 configuration (bit-comparable with the oracle); in the bf16
+// configuration, which is specified to a tolerance, the hardware exp2 / rcp (<= 2 ulp) -- the mask head alone evaluates
+// 67 M sigmoids per call of the bench, and the polynomial exp plus an IEEE division made it VALU-bound
+template <class P>
+__device__ __forceinline__ float head_sigmoid(float x) {
+    if (P::kPrec == kBf16) return fast_sigmoid(x);
+    return kns_sigmoid(x);
+}
 __device__ __forceinline__ float fast_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.88539008177792681f));
 }

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float x = v[i] + bias;
-                    if (kSigmoid) x = kns_sigmoid(x);
+                    if (kSigmoid) x = head_sigmoid<P>(x);
                     if (kApack && col >= g.n_valid) x = 0.0f;
                     v[i] = x;
                 }
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wsr_kernel(GemmArgs g) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             float x = v[i] + bias[q * NU + j];
-                            if (kSigmoid) x = kns_sigmoid(x);
+                            if (kSigmoid) x = head_sigmoid<P>(x);
                             if (kApack && nt * 16 + colq >= g.n_valid) x = 0.0f;
                             v[i] = x;
                         }
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(512, 2) void gemm_head_kernel(GemmArgs g) {
                 if (nt * 16 < g.n_valid) {  // an n-tile made of padding columns only needs no sigmoid
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float x = kns_sigmoid(acc[j][i] + bias[nt]);
+                        const float x = head_sigmoid<PBF16>(acc[j][i] + bias[nt]);
                         v[i] = nt * 16 + colq < g.n_valid ? x : 0.0f;
                     }
                 }
