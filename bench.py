@@ -40,9 +40,14 @@ MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}  # dense peaks, no sparsity
 H = 271
 G3 = 813
 HEADS = (1, 5, 40, 257)
-# algorithmic work per stream-frame (unpadded dims)
-BYTES_ANALYSIS = 512 + 512 + 512 + 2056 + 1028
-BYTES_SYNTHESIS = 2056 + 1028 + 1024 + 1024 + 512
+# algorithmic work per stream-frame (unpadded dims).  STFT stages, SURVEY.md 8d dataflow (spectrum stored as fp32 and read
+# back, fp32 features, history / tail through HBM every frame) ...
+SURVEY_BYTES_ANALYSIS = 512 + 512 + 512 + 2056 + 1028
+SURVEY_BYTES_SYNTHESIS = 2056 + 1028 + 1024 + 1024 + 512
+# ... and the dataflow of this engine since round 2: no stored spectrum in multi-frame calls (the
+# synthesis kernel rebuilds it from the PCM), operand-typed features, history and overlap-add tail stay on chip inside a call
+BYTES_ANALYSIS = {'bf16': 512 + 257 * 2, 'fp32': 512 + 257 * 4}      # PCM in, features out
+BYTES_SYNTHESIS = 512 + 257 * 4 + 512                                # PCM in, fp32 mask in, PCM out
 MAC_GEMM_IN = (271 + 272 + 276 + 311 + 4 * 271) * G3      # 8 input-side GEMMs (W_ih)
 MAC_GRU = 8 * H * G3                                      # 8 recurrent GEMMs (W_hh)
 MAC_HEAD = 257 * H + H * sum(HEADS)                       # front-end + 4 heads
@@ -281,7 +286,7 @@ def main():
     kb.profile_enable(False)
     frames_per_launch = B * T
     work = {
-        'analysis': ('hbm', BYTES_ANALYSIS * frames_per_launch, 1),
+        'analysis': ('hbm', BYTES_ANALYSIS[args.precision] * frames_per_launch, 1),
         'gemm_input': ('mfma', 2.0 * MAC_GEMM_IN / 8 * frames_per_launch, 8),
         'gru_recurrent': ('mfma', 2.0 * MAC_GRU / 8 * frames_per_launch, 8),
         'gemm_head': ('mfma', 2.0 * MAC_HEAD / 5 * frames_per_launch, 5),
@@ -306,6 +311,13 @@ def main():
                         'frac': round(achieved / peak, 5), 'avg_launch_ms': round(ms, 5),
                         'launches_per_step': round(actual, 2) if actual != int(actual) else int(actual),
                         'share_of_device_time': round(ms * actual / dev_ms, 4) if dev_ms else None}
+        if name in ('analysis', 'synthesis'):
+            # these two are limited by VALU issue, not by HBM: `frac` prices the bytes the dataflow
+            # needs; the round-1 figure (SURVEY's dataflow, which stored the spectrum) is kept for comparison
+            sv = (SURVEY_BYTES_ANALYSIS if name == 'analysis' else SURVEY_BYTES_SYNTHESIS) * frames_per_launch
+            stages[name]['frac_by_survey_dataflow_bytes'] = round(sv / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            stages[name]['limited_by'] = 'VALU issue'
+
     dominant = max(stages, key=lambda k: stages[k]['avg_launch_ms'] * stages[k]['launches_per_step'])
     # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command (tools/pmc_run.sh ->
     # profiles/*_pmc.json; FETCH_SIZE doubled per the gfx950 correction); they cannot be collected inside a timed run.
