@@ -213,12 +213,12 @@ __all__ = ["write_params", "read_params", "make_random", "make_gate", "make_adap
            "tensor_order"]
 
 
-def make_adaptive_gate(mu: float = -9.0, sigma: float = 0.125, a: float = 0.5, c0: float = 0.9, s: float = 41.0,
-                       bz: float = 2.2, kappa: float = 1.0, g: float = 24.75, thr: float = 0.24, z_d: float = 0.1,
-                       g2: float = 1.69, z_b: float = 0.64, g3: float = 4.2, b3: float = 0.0,
-                       spread: float = 0.416, thr_lf: float = 0.45, lf_bands: float = 1.6, zb_rel: float = 3.6,
+def make_adaptive_gate(mu: float = -9.0, sigma: float = 0.125, a: float = 0.5, c0: float = 0.9, s: float = 51.25,
+                       bz: float = 2.75, kappa: float = 1.0, g: float = 22.275, thr: float = 0.24, z_d: float = 0.1,
+                       g2: float = 1.521, z_b: float = 0.64, g3: float = 8.25, b3: float = -0.85,
+                       spread: float = 0.416, thr_lf: float = 0.405, lf_bands: float = 1.6, zb_rel: float = 3.6,
                        ctx: float = 0.0, ctx_width: int = 8, hang: float = 0.3, hang_lo: int = 8, hang_hi: int = 100,
-                       hang_gain: float = 4.86, hang_ref: float = 0.81, hang_z0: float = 6.8, hang_z1: float = 9.0,
+                       hang_gain: float = 4.374, hang_ref: float = 0.81, hang_z0: float = 6.8, hang_z1: float = 9.0,
                        hang_bands: int = 4) -> Dict[str, np.ndarray]:
     """
     Hand-built spectral gate with an ADAPTIVE noise floor carried in GRU state -- nothing in it is derived from any audio
@@ -242,7 +242,8 @@ def make_adaptive_gate(mu: float = -9.0, sigma: float = 0.125, a: float = 0.5, c
                 output of bands hang_lo..hang_hi; while it is up it lowers the threshold of the lowest `hang_bands` bands
                 by `hang` -- a voiced sound that has only its fundamental left is kept, a thump in noise is not.
                 layer B, unit k < 257: n = tanh(g2 d_band(k)), update gate sigmoid(logit(z_b) - zb_rel d): fast attack,
-                slow release; head: mask_k = sigmoid(g3 h_k + b3).
+                slow release; head: mask_k = sigmoid(g3 h_k + b3); b3 < 0 so that a freshly reset stream (h = 0) starts
+                at mask 0.3 rather than 0.5 (a design choice, made before and kept out of the constant search).
       stages 1-3 carry zero weights.
     """
     t = {name: np.zeros(shape, np.float32) for name, shape in tensor_order()}
