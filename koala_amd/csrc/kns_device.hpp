@@ -371,6 +371,22 @@ __device__ __forceinline__ void buf_store_gi(__amdgpu_buffer_rsrc_t r, unsigned 
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
 }
 
+// a * b + c of the bf16 configuration's gate arithmetic: fused (what the spec and the oracle write: n = tanh(fma(r, gh_n,
+// gi_n)), h' = fma(z, h - n, n)); -DKNS_GATE_UNFUSED restores round 1's separate multiply and add for A/B runs
+__device__ __forceinline__ f32x2 gate_fma2(f32x2 a, f32x2 b, f32x2 c) {
+#ifdef KNS_GATE_UNFUSED
+    return a * b + c;
+#else
+    return __builtin_elementwise_fma(a, b, c);
+#endif
+}
+__device__ __forceinline__ float gate_fma1(float a, float b, float c) {
+#ifdef KNS_GATE_UNFUSED
+    return a * b + c;
+#else
+    return __builtin_fmaf(a, b, c);
+#endif
+}
 __device__ __forceinline__ f32x2 fast_sigmoid2(f32x2 x) {
     f32x2 e = x * f32x2{-1.44269504088896341f, -1.44269504088896341f};
     e = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + f32x2{1.0f, 1.0f};
@@ -380,7 +396,7 @@ __device__ __forceinline__ f32x2 fast_tanh2(f32x2 x) {
     f32x2 e = x * f32x2{2.88539008177792681f, 2.88539008177792681f};
     e = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + f32x2{1.0f, 1.0f};
     f32x2 r = f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
-    return f32x2{1.0f, 1.0f} - (r + r);
+    return gate_fma2(r, f32x2{-2.0f, -2.0f}, f32x2{1.0f, 1.0f});  // 1 - 2 r (exact doubling: the same value as 1 - (r + r))
 }
 
 }  // namespace kns

@@ -101,9 +101,9 @@ __global__ __launch_bounds__(64 * W, W / 4) void gru_kernel(GruArgs g) {
                         const f32x2 xr = {ir[2 * p], ir[2 * p + 1]}, xz = {iz[2 * p], iz[2 * p + 1]}, xn = {in[2 * p], in[2 * p + 1]};
                         const f32x2 r = fast_sigmoid2(xr + (ar + vbr));
                         const f32x2 z = fast_sigmoid2(xz + (az + vbz));
-                        const f32x2 n = fast_tanh2(r * (an + vbn) + xn);
+                        const f32x2 n = fast_tanh2(gate_fma2(r, an + vbn, xn));
                         const f32x2 hp = {hreg[q][2 * p], hreg[q][2 * p + 1]};
-                        const f32x2 h = z * (hp - n) + n;
+                        const f32x2 h = gate_fma2(z, hp - n, n);
                         hreg[q][2 * p] = h[0];
                         hreg[q][2 * p + 1] = h[1];
                     }
@@ -225,9 +225,9 @@ __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
                         xn = {gin[2][2 * p], gin[2][2 * p + 1]};
             const f32x2 r = fast_sigmoid2(xr + (ar + vbr));
             const f32x2 z = fast_sigmoid2(xz + (az + vbz));
-            const f32x2 n = fast_tanh2(r * (an + vbn) + xn);
+            const f32x2 n = fast_tanh2(gate_fma2(r, an + vbn, xn));
             const f32x2 hp = {hown[2 * p], hown[2 * p + 1]};
-            const f32x2 h = z * (hp - n) + n;
+            const f32x2 h = gate_fma2(z, hp - n, n);
             hnew[2 * p] = h[0];
             hnew[2 * p + 1] = h[1];
         }
@@ -425,9 +425,9 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
                 const f32x2 xr = {ir[2 * p], ir[2 * p + 1]}, xz = {iz[2 * p], iz[2 * p + 1]}, xn = {in[2 * p], in[2 * p + 1]};
                 const f32x2 r = fast_sigmoid2(xr + (ar + vbr));
                 const f32x2 z = fast_sigmoid2(xz + (az + vbz));
-                const f32x2 n = fast_tanh2(r * (an + vbn) + xn);
+                const f32x2 n = fast_tanh2(gate_fma2(r, an + vbn, xn));
                 const f32x2 hp = {hreg[q][2 * p], hreg[q][2 * p + 1]};
-                const f32x2 h = z * (hp - n) + n;
+                const f32x2 h = gate_fma2(z, hp - n, n);
                 hnew[2 * p] = h[0];
                 hnew[2 * p + 1] = h[1];
             }
@@ -476,9 +476,9 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
                 // same operations, element by element, as the packed gate math above
                 const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((xr + (ar + br)) * -1.44269504088896341f));
                 const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((xz + (az + bz)) * -1.44269504088896341f));
-                const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((r * (an + bn) + xn) * 2.88539008177792681f));
-                const float n = 1.0f - (rr + rr);
-                h16 = z * (h16 - n) + n;
+                const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gate_fma1(r, an + bn, xn) * 2.88539008177792681f));
+                const float n = gate_fma1(rr, -2.0f, 1.0f);
+                h16 = gate_fma1(z, h16 - n, n);
                 put_h16(hn, h16);
             }
         }
