@@ -387,6 +387,29 @@ __device__ __forceinline__ float gate_fma1(float a, float b, float c) {
     return __builtin_fmaf(a, b, c);
 #endif
 }
+// (float) half HI of the packed fp16 pair x, plus t / times-and-plus: one v_fma_mix_f32 each, one rounding
+template <int HI>
+__device__ __forceinline__ float mix_add(unsigned x, float t) {
+    float d;
+    if (HI)
+        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(x), "v"(t));
+    else
+        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(x), "v"(t));
+    return d;
+}
+template <int HI>
+__device__ __forceinline__ float mix_fma(float a, float b, unsigned x) {
+#ifdef KNS_GATE_UNFUSED
+    return a * b + (float) __builtin_bit_cast(_Float16, (unsigned short) (HI ? x >> 16 : x));
+#else
+    float d;
+    if (HI)
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(x));
+    else
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(x));
+    return d;
+#endif
+}
 __device__ __forceinline__ f32x2 fast_sigmoid2(f32x2 x) {
     f32x2 e = x * f32x2{-1.44269504088896341f, -1.44269504088896341f};
     e = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + f32x2{1.0f, 1.0f};

@@ -411,7 +411,16 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
             (const P::gi_t *) g.gi + ((size_t) (t + 1 < g.T ? t + 1 : t) * g.mtiles + mt) * kGateTiles * 64, kGateTiles * 512);
 
         auto gates = [&](const int q, const int u, f32x4 (&acc)[3]) {
+#ifdef KNS_GATE_NO_MIX
             const f32x4 ir = P::from_gi(gi[q][0]), iz = P::from_gi(gi[q][1]), in = P::from_gi(gi[q][2]);
+#else
+            // the fp16 pre-activations enter the gate arithmetic through v_fma_mix_f32 (an f16 operand of an f32 fma):
+            // x + t as fma(x, 1, t) and fma(r, q, x) round once, exactly like the add / fma on the converted value, so
+            // the results are the same bit for bit and twelve conversions per tile are gone
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 pr = __builtin_bit_cast(u32x2, gi[q][0]), pz = __builtin_bit_cast(u32x2, gi[q][1]),
+                        pn = __builtin_bit_cast(u32x2, gi[q][2]);
+#endif
 #pragma unroll
             for (int gt = 0; gt < 3; ++gt) gi[q][gt] = buf_load_gi(gnext, lane8, (u * 3 + gt) * 512u);
             const float br = lbias[(u * 3 + 0) * 16 + colq], bz = lbias[(u * 3 + 1) * 16 + colq],
@@ -422,10 +431,17 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
             for (int p = 0; p < 2; ++p) {
                 const f32x2 ar = {acc[0][2 * p], acc[0][2 * p + 1]}, az = {acc[1][2 * p], acc[1][2 * p + 1]},
                             an = {acc[2][2 * p], acc[2][2 * p + 1]};
+#ifdef KNS_GATE_NO_MIX
                 const f32x2 xr = {ir[2 * p], ir[2 * p + 1]}, xz = {iz[2 * p], iz[2 * p + 1]}, xn = {in[2 * p], in[2 * p + 1]};
                 const f32x2 r = fast_sigmoid2(xr + (ar + vbr));
                 const f32x2 z = fast_sigmoid2(xz + (az + vbz));
                 const f32x2 n = fast_tanh2(gate_fma2(r, an + vbn, xn));
+#else
+                const f32x2 tr = ar + vbr, tz = az + vbz, tn = an + vbn;
+                const f32x2 r = fast_sigmoid2(f32x2{mix_add<0>(pr[p], tr[0]), mix_add<1>(pr[p], tr[1])});
+                const f32x2 z = fast_sigmoid2(f32x2{mix_add<0>(pz[p], tz[0]), mix_add<1>(pz[p], tz[1])});
+                const f32x2 n = fast_tanh2(f32x2{mix_fma<0>(r[0], tn[0], pn[p]), mix_fma<1>(r[1], tn[1], pn[p])});
+#endif
                 const f32x2 hp = {hreg[q][2 * p], hreg[q][2 * p + 1]};
                 const f32x2 h = gate_fma2(z, hp - n, n);
                 hnew[2 * p] = h[0];
