@@ -51,6 +51,12 @@ LoadResult load_params(const char *path, Params *p, std::string *err) {
         *err = std::string("`") + path + "` is not a Koala (KNS1) model file.";
         return kLoadFormat;
     }
+    if (hdr[11] > 1) {  // oracle-only extension (oracle/kns_oracle.h): a front-end over several feature frames
+        fclose(f);
+        *err = std::string("`") + path + "` has a front-end over " + std::to_string(hdr[11]) +
+               " feature frames: this engine implements KNS-v1 (one frame).";
+        return kLoadFormat;
+    }
     const size_t G3 = 3 * kHidden;
     ok = read_vec(f, &p->mean, kBins) && read_vec(f, &p->scale, kBins) && read_vec(f, &p->w_in, (size_t) kBins * kHidden) &&
          read_vec(f, &p->b_in, kHidden);

@@ -34,8 +34,10 @@ G3 = 3 * HIDDEN
 MAGIC = b"KNS1\0\0\0\0"
 
 
-def tensor_order():
-    names = [("mean", (BINS,)), ("scale", (BINS,)), ("w_in", (BINS, HIDDEN)), ("b_in", (HIDDEN,))]
+def tensor_order(front_taps: int = 1):
+    """`front_taps` > 1: oracle-only extension (a front-end over the last N feature frames, oldest first); the GPU engine
+    and KNS-v1 proper have 1."""
+    names = [("mean", (BINS,)), ("scale", (BINS,)), ("w_in", (front_taps * BINS, HIDDEN)), ("b_in", (HIDDEN,))]
     for s in range(STAGES):
         d_in = HEADS[s - 1] if s else 0
         names += [
@@ -50,10 +52,11 @@ def tensor_order():
 
 def write_params(path: str, tensors: Dict[str, np.ndarray]) -> None:
     tmp = path + ".tmp%d" % os.getpid()
+    front_taps = int(np.asarray(tensors["w_in"]).shape[0]) // BINS
     with open(tmp, "wb") as f:
         f.write(MAGIC)
-        f.write(struct.pack("<14I", 1, N_FFT, HOP, BINS, HIDDEN, STAGES, *HEADS, DELAY, 0, 0, 0))
-        for name, shape in tensor_order():
+        f.write(struct.pack("<14I", 1, N_FFT, HOP, BINS, HIDDEN, STAGES, *HEADS, DELAY, front_taps if front_taps > 1 else 0, 0, 0))
+        for name, shape in tensor_order(front_taps):
             a = np.ascontiguousarray(tensors[name], dtype="<f4")
             if a.shape != shape:
                 raise ValueError("tensor %s has shape %s, expected %s" % (name, a.shape, shape))
@@ -69,7 +72,7 @@ def read_params(path: str) -> Dict[str, np.ndarray]:
         if hdr[:10] != (1, N_FFT, HOP, BINS, HIDDEN, STAGES) + HEADS:
             raise ValueError("unsupported KNS1 dims: %r" % (hdr,))
         out = {}
-        for name, shape in tensor_order():
+        for name, shape in tensor_order(max(1, hdr[11])):
             n = int(np.prod(shape))
             out[name] = np.frombuffer(f.read(4 * n), dtype="<f4").reshape(shape).copy()
         if f.read(1):

@@ -59,7 +59,9 @@ class Hypothesis(NamedTuple):
     bias_shift: int = 5          # b = int8 * 2^-bias_shift
     front_shift: int = 7         # front-end weights
     front_bias_shift: int = 5
-    front_tap: int = 4           # which of the 5 stacked frames KNS-v1's one-frame front-end keeps (0..4), or -1 = their sum
+    front_tap: int = 4           # which of the 5 stacked frames KNS-v1's one-frame front-end keeps (0..4), -1 = their sum,
+                                 # 5 = ALL five, file order = oldest first; 6 = all five, file order = newest first (both give a
+                                 # 5-frame front-end that only the CPU oracle can run: oracle/kns_oracle.h)
     mean_div: float = 512.0      # feature mean = table / mean_div ...
     scale_div: float = 4096.0    # ... feature scale = table / scale_div
     log2_features: bool = False  # tables in log2 units: mean and 1/scale are multiplied by ln 2 to reach KNS-v1's ln
@@ -107,7 +109,8 @@ def read_pv(path: str) -> PvModel:
 
 def to_kns1(model: PvModel, hyp: Hypothesis = Hypothesis()) -> Dict[str, np.ndarray]:
     """All 21 records of the reference file as KNS1 tensors under `hyp` (see the module docstring: a hypothesis, not parity)."""
-    t = {name: np.zeros(shape, np.float32) for name, shape in params.tensor_order()}
+    taps = FRONT_TAPS if hyp.front_tap >= FRONT_TAPS else 1
+    t = {name: np.zeros(shape, np.float32) for name, shape in params.tensor_order(taps)}
     ln2 = float(np.log(2.0))
     mean = model.table_mean.astype(np.float64) / hyp.mean_div
     scale = model.table_scale.astype(np.float64) / hyp.scale_div
@@ -116,7 +119,10 @@ def to_kns1(model: PvModel, hyp: Hypothesis = Hypothesis()) -> Dict[str, np.ndar
     t['mean'][:] = mean
     t['scale'][:] = scale
     fw = model.front.weights.astype(np.float64).reshape(FRONT_TAPS, params.BINS, params.HIDDEN) * 2.0 ** -hyp.front_shift
-    t['w_in'][:] = fw.sum(axis=0) if hyp.front_tap < 0 else fw[hyp.front_tap]
+    if hyp.front_tap >= FRONT_TAPS:
+        t['w_in'][:] = (fw if hyp.front_tap == FRONT_TAPS else fw[::-1]).reshape(FRONT_TAPS * params.BINS, params.HIDDEN)
+    else:
+        t['w_in'][:] = fw.sum(axis=0) if hyp.front_tap < 0 else fw[hyp.front_tap]
     t['b_in'][:] = model.front.trailer.astype(np.float64) * 2.0 ** -hyp.front_bias_shift
     perm = np.concatenate([np.arange(params.HIDDEN) + hyp.gate_order.index(gate) * params.HIDDEN for gate in 'rzn'])
     it = iter(model.blocks)

@@ -130,6 +130,7 @@ typedef struct {
 
 struct kns_params {
     int precision;
+    int front_taps; /* feature frames the front-end sees (1 = KNS-v1; > 1: oracle-only extension, see kns_oracle.h) */
     int head[KNS_STAGES];
     int delay;
     float *blob;
@@ -160,7 +161,13 @@ int kns_params_load(const char *path, int precision, kns_params_t **out) {
     kns_params_t *p = (kns_params_t *) calloc(1, sizeof(*p));
     p->precision = precision;
     p->delay = (int) hdr[10];
-    size_t total = 2 * KNS_BINS + (size_t) KNS_BINS * KNS_H + KNS_H;
+    p->front_taps = hdr[11] > 1 ? (int) hdr[11] : 1;
+    if (p->front_taps > KNS_MAX_FRONT_TAPS) {
+        fclose(f);
+        free(p);
+        return -2;
+    }
+    size_t total = 2 * KNS_BINS + (size_t) p->front_taps * KNS_BINS * KNS_H + KNS_H;
     for (int s = 0; s < KNS_STAGES; ++s) {
         p->head[s] = (int) hdr[6 + s];
         int d_in = s ? p->head[s - 1] : 0;
@@ -185,7 +192,7 @@ int kns_params_load(const char *path, int precision, kns_params_t **out) {
     } while (0)
     TAKE(p->mean, KNS_BINS, 0);
     TAKE(p->scale, KNS_BINS, 0);
-    TAKE(p->w_in, KNS_BINS * KNS_H, 1);
+    TAKE(p->w_in, p->front_taps * KNS_BINS * KNS_H, 1);
     TAKE(p->b_in, KNS_H, 0);
     for (int s = 0; s < KNS_STAGES; ++s) {
         kns_stage_t *st = &p->st[s];
@@ -306,6 +313,10 @@ typedef struct {
     int16_t hist[KNS_FRAME];
     float tail[KNS_FRAME];
     float h[2 * KNS_STAGES][KNS_H];
+    /* front-end context (front_taps > 1 only): the features of the previous frames, newest last; `seen` frames are valid,
+     * the rest stand for silence */
+    float fhist[KNS_MAX_FRONT_TAPS - 1][KNS_BINS];
+    int seen;
 } kns_stream_t;
 
 struct kns_oracle {
@@ -429,6 +440,7 @@ static void gru_block(int nb, const float *x, int ldx, int K, const float *w_ih,
 }
 
 typedef struct {
+    float fstack[KNS_MAX_BLOCK][KNS_MAX_FRONT_TAPS * KNS_BINS]; /* [oldest ... newest] feature frames */
     float feat[KNS_MAX_BLOCK][KNS_BINS];
     float spec[KNS_MAX_BLOCK][KNS_BINS * 2];
     float xin[KNS_MAX_BLOCK][KNS_H + 64]; /* [y_prev ; e] */
@@ -445,7 +457,28 @@ static void frame_block(const kns_params_t *p, int nb, kns_stream_t **st, const 
         analysis(p, st[s]->hist, pcm[s], w->spec[s], w->feat[s]);
         memcpy(st[s]->hist, pcm[s], sizeof(int16_t) * KNS_FRAME);
     }
-    gemm_block(nb, &w->feat[0][0], KNS_BINS, KNS_BINS, p->w_in, KNS_H, p->b_in, &w->e[0][0], KNS_H, bf);
+    if (p->front_taps == 1) {
+        gemm_block(nb, &w->feat[0][0], KNS_BINS, KNS_BINS, p->w_in, KNS_H, p->b_in, &w->e[0][0], KNS_H, bf);
+    } else { /* oracle-only extension: the front-end sees the last `front_taps` feature frames, oldest first */
+        const int ht = p->front_taps - 1;
+        for (int s = 0; s < nb; ++s) {
+            for (int j = 0; j < ht; ++j) {
+                float *dst = &w->fstack[s][(size_t) j * KNS_BINS];
+                const int age = ht - j; /* frames back */
+                if (age <= st[s]->seen) {
+                    memcpy(dst, st[s]->fhist[ht - age], sizeof(float) * KNS_BINS);
+                } else { /* before the stream began: the feature of a silent frame */
+                    for (int k = 0; k < KNS_BINS; ++k) dst[k] = (kns_log(1e-10f) - p->mean[k]) * p->scale[k];
+                }
+            }
+            memcpy(&w->fstack[s][(size_t) ht * KNS_BINS], w->feat[s], sizeof(float) * KNS_BINS);
+            memmove(st[s]->fhist[0], st[s]->fhist[1], sizeof(float) * KNS_BINS * (size_t) (ht - 1));
+            memcpy(st[s]->fhist[ht - 1], w->feat[s], sizeof(float) * KNS_BINS);
+            if (st[s]->seen < ht) st[s]->seen++;
+        }
+        gemm_block(nb, &w->fstack[0][0], KNS_MAX_FRONT_TAPS * KNS_BINS, p->front_taps * KNS_BINS, p->w_in, KNS_H, p->b_in,
+                   &w->e[0][0], KNS_H, bf);
+    }
     if (bf)
         for (int s = 0; s < nb; ++s)
             for (int j = 0; j < KNS_H; ++j) w->e[s][j] = kns_round_bf16(w->e[s][j]);

@@ -33,6 +33,11 @@ extern "C" {
 #define KNS_H 271
 #define KNS_STAGES 4
 #define KNS_G3 (3 * KNS_H)
+/* Oracle-only extension: the front-end may see the last N feature frames (KNS1 header word 11; w_in then has N * 257 rows,
+ * oldest frame first).  The reference's model file has such a front-end (N = 5, koala_params.pv record [1285, 271]); KNS-v1
+ * and the GPU engine have N = 1.  Used by tools/pv_hypotheses.py to find out whether the missing context is what keeps
+ * imported weights from behaving. */
+#define KNS_MAX_FRONT_TAPS 5
 #define KNS_MAX_BLOCK 64 /* streams that share one pass over the weights in kns_oracle_process */
 
 /* precision modes: which rounding points of the GPU pipeline are emulated */

@@ -1,5 +1,5 @@
 for rep in 1 2; do
-  for lib in build/libpv_koala_nomix.so build/libpv_koala_mix.so; do
+  for lib in build/libpv_koala_mix.so koala_amd/lib/libpv_koala.so; do
     python bench.py --library $PWD/$lib --no-cpu-baseline --no-extra --steps 400 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])

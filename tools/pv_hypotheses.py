@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 PV = '/root/reference/lib/common/koala_params.pv'
 
 SPACE = dict(weight_shift=[5, 6, 7, 8, 9], bias_shift=[3, 4, 5, 6, 7], front_shift=[5, 6, 7, 8, 9], front_bias_shift=[3, 4, 5, 6, 7],
-             front_tap=[-1, 0, 1, 2, 3, 4], mean_div=[256.0, 512.0, 1024.0], scale_div=[2048.0, 4096.0, 8192.0],
+             front_tap=[-1, 0, 4, 5, 5, 5, 6, 6, 6], mean_div=[256.0, 512.0, 1024.0], scale_div=[2048.0, 4096.0, 8192.0],
              log2_features=[False, True], gate_order=[''.join(p) for p in itertools.permutations('rzn')], y_first=[True, False],
              head_shift=[5, 6, 7, 8], head_bias_shift=[3, 4, 5, 6])
 
@@ -66,6 +66,29 @@ def main():
         hyps.append({k: rnd.choice(v) for k, v in SPACE.items()})
     with mp.Pool(min(8, os.cpu_count() or 1)) as pool:
         results = pool.map(evaluate, hyps, chunksize=8)
+        # second phase: coordinate descent (one field at a time, all its values) from the best random hypotheses
+        def sc(d):
+            return max(d['speech'], d['noise'], d['mixed'])
+        ranked = sorted(results, key=lambda r: sc(r[1]))
+        descents = []
+        for start, _ in ranked[:4]:
+            cur = dict(start)
+            best = sc(evaluate(cur)[1])
+            steps = 0
+            while True:
+                cands = []
+                for k, vals in SPACE.items():
+                    for v in dict.fromkeys(vals):
+                        if cur.get(k, getattr(__import__('koala_amd.pv_import', fromlist=['Hypothesis']).Hypothesis(), k)) != v:
+                            h = dict(cur)
+                            h[k] = v
+                            cands.append(h)
+                res = pool.map(evaluate, cands, chunksize=4)
+                h, d = min(res, key=lambda r: sc(r[1]))
+                if sc(d) >= best - 1e-4:
+                    break
+                best, cur, steps = sc(d), h, steps + 1
+            descents.append({'hypothesis': cur, 'metrics': evaluate(cur)[1], 'descent_steps': steps})
     scored = sorted(results, key=lambda r: max(r[1]['speech'], r[1]['noise'], r[1]['mixed']))
     scores = np.array([max(r[1]['speech'], r[1]['noise'], r[1]['mixed']) for r in scored])
     # "behaves like a suppressor": removes >= 6 dB of the noise while keeping speech within 3 dB
@@ -78,6 +101,7 @@ def main():
         'suppressor_like': len(useful),
         'default_hypothesis': {'hypothesis': results[0][0], 'metrics': results[0][1]},
         'best': [{'hypothesis': h, 'metrics': d} for h, d in scored[:10]],
+        'coordinate_descent_from_the_best_four': descents,
         'best_suppressor_like': [{'hypothesis': h, 'metrics': d} for h, d in sorted(useful, key=lambda r: r[1]['noise_gain_db'])[:5]],
     }
     path = os.path.join(ROOT, 'profiles', 'r02_pv_import_search.json')
