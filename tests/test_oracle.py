@@ -196,3 +196,48 @@ def test_blocked_gemm_equals_the_plain_statement(random_model, tmp_path):
         subprocess.run([sys.executable, '-c', script, str(tmp_path / tag)], env=dict(os.environ, **env), check=True, timeout=600)
     for prec in (0, 1):
         assert np.array_equal(np.load(tmp_path / ('blocked_%d.npy' % prec)), np.load(tmp_path / ('simple_%d.npy' % prec)))
+
+
+def test_front_end_context_extension(random_model, tmp_path):
+    """Oracle-only extension (kns_oracle.h: the front-end sees the last N feature frames, oldest first): with zero
+    weights on the older frames it is the one-frame model bit for bit; with the weight on the frame before, the
+    embedding tap is the one-frame model's embedding of that earlier frame; and the product library refuses such a
+    file by name (it implements KNS-v1 proper)."""
+    import ctypes as C
+    from koala_amd import params
+    from koala_amd import _util
+    t = params.read_params(random_model)
+    x = synth_streams(3, 6, seed=4)
+    base = oracle.Oracle(random_model, 3).process(x)
+    t5 = dict(t)
+    w = np.zeros((5 * params.BINS, params.HIDDEN), np.float32)
+    w[4 * params.BINS:] = t['w_in']
+    t5['w_in'] = w
+    p5 = str(tmp_path / 'taps5.kns')
+    params.write_params(p5, t5)
+    assert np.array_equal(oracle.Oracle(p5, 3).process(x), base)
+    # weight on the previous frame only: embed(t) of this model == embed(t - 1) of the one-frame model
+    t2 = dict(t)
+    w = np.zeros((2 * params.BINS, params.HIDDEN), np.float32)
+    w[:params.BINS] = t['w_in']
+    t2['w_in'] = w
+    p2 = str(tmp_path / 'taps2.kns')
+    params.write_params(p2, t2)
+    o1, o2 = oracle.Oracle(random_model), oracle.Oracle(p2)
+    prev = None
+    for f in range(4):
+        frame = x[0, f * 256:(f + 1) * 256]
+        _, tap1 = o1.process_tap(frame)
+        _, tap2 = o2.process_tap(frame)
+        if prev is not None:
+            assert np.array_equal(tap2['embed'], prev)
+        prev = tap1['embed'].copy()
+    lib = C.CDLL(_util.build_native())
+    lib.pv_koala_init.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+    lib.pv_get_error_stack.argtypes = [C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.c_int32)]
+    h = C.c_void_p()
+    assert lib.pv_koala_init(b'key', p5.encode(), b'best', C.byref(h)) == 2
+    ref, depth = C.POINTER(C.c_char_p)(), C.c_int32()
+    lib.pv_get_error_stack(C.byref(ref), C.byref(depth))
+    assert b'front-end over 5 feature frames' in ref[0]
+    lib.pv_free_error_stack(ref)
