@@ -3,7 +3,7 @@ Parity of the HIP engine (through the C ABI of libpv_koala.so) with the CPU orac
 
 Bars (BASELINE.json north_star / DESIGN.md section 5):
   fp32 engine : int16 PCM within +-1 LSB of the fp32 oracle; spectrum/feature/mask taps within 2e-5 / 1e-4 / 2e-5
-  bf16 engine : mask within 1e-3 RMS of the fp32 oracle; PCM within 6 LSB of the oracle run with the same
+  bf16 engine : mask within 1e-3 RMS of the fp32 oracle; PCM within 4 LSB of the oracle run with the same
                 rounding points (bf16 GEMM operands, fp16 pre-activations), >= 99 % of samples within 1 LSB
 Size-independent properties are checked at BASELINE's full batch (4096 streams).
 """
@@ -15,6 +15,12 @@ from conftest import model_file, synth_streams
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
+
+import os as _os
+# bf16 engine vs the oracle with the same rounding points: the two differ only in the gate / head / log transcendentals
+# (hardware v_exp / v_rcp / v_log against the spec's polynomials).  Largest difference ever measured in this suite: see
+# DESIGN.md section 5.
+BF16_TOL = int(_os.environ.get('KOALA_TEST_BF16_TOL', '4'))  # measured maximum 3 LSB
 
 
 def run_oracle(model, x, precision=oracle.PREC_FP32):
@@ -86,7 +92,7 @@ def test_bf16_against_both_oracles(random_model, test_pcm):
     d = lsb(out, run_oracle(random_model, x, oracle.PREC_BF16))
     hist = np.bincount(np.minimum(d.ravel(), 8), minlength=9)
     print('bf16 engine vs bf16-rounding oracle, |diff| histogram 0..8+:', hist.tolist(), 'mask rms vs fp32:', rms)
-    assert d.max() <= 6 and (d == 0).mean() > 0.75 and (d <= 1).mean() > 0.99
+    assert d.max() <= BF16_TOL and (d == 0).mean() > 0.75 and (d <= 1).mean() > 0.99
     assert lsb(out, run_oracle(random_model, x)).max() <= 24  # against the unrounded oracle
 
 
@@ -229,7 +235,7 @@ def test_ragged_large_batches_take_the_fallback_kernels(random_model, precision,
     o = oracle.Oracle(random_model, 8, oracle.PREC_BF16 if precision == 'bf16' else oracle.PREC_FP32)
     ref = np.concatenate([o.process(base), o.process(base)], axis=1)
     got = np.concatenate([y[:8], y2[:8]], axis=1)
-    assert lsb(got, ref).max() <= (6 if precision == 'bf16' else 1)
+    assert lsb(got, ref).max() <= (BF16_TOL if precision == 'bf16' else 1)
 
 
 @pytest.mark.parametrize('kind', ['random', 'gate', 'adaptive'])
@@ -240,7 +246,7 @@ def test_against_committed_golden_vectors(kind):
     from conftest import GOLDEN
     g = np.load(os.path.join(GOLDEN, 'kns_v1_golden.npz'))
     model = model_file(kind)
-    for precision, tol in (('fp32', 1), ('bf16', 6)):
+    for precision, tol in (('fp32', 1), ('bf16', BF16_TOL)):
         kb = koala_amd.create_batch('key', 3, 16, precision, model_path=model)
         y = np.concatenate([kb.process(np.ascontiguousarray(g['pcm'][:, c * 4096:(c + 1) * 4096])) for c in range(3)], axis=1)
         kb.delete()
@@ -297,7 +303,7 @@ def test_random_call_sequences_keep_the_stream_state_straight(random_model, prec
     torch = pytest.importorskip('torch')
     rng = np.random.default_rng(42)
     prec = oracle.PREC_BF16 if precision == 'bf16' else oracle.PREC_FP32
-    tol = 6 if precision == 'bf16' else 1
+    tol = BF16_TOL if precision == 'bf16' else 1
     kb = koala_amd.create_batch('key', B, Tmax, precision, model_path=random_model)
     ref = oracle.Oracle(random_model, B, prec)
     worst = 0
@@ -339,7 +345,7 @@ def test_long_chunks_of_small_and_odd_batches(random_model, precision, B, T):
     kb.delete()
     ref = oracle.Oracle(random_model, B, oracle.PREC_BF16 if precision == 'bf16' else oracle.PREC_FP32)
     want, want2 = ref.process(x), ref.process(x)
-    tol = 6 if precision == 'bf16' else 1
+    tol = BF16_TOL if precision == 'bf16' else 1
     assert lsb(y, want).max() <= tol and lsb(y2, want2).max() <= tol
 
 
@@ -375,7 +381,7 @@ def test_distinct_handles_on_distinct_threads(random_model):
     for t in threads:
         t.join()
     assert not errors, errors
-    assert lsb(results['b32'], want['fp32']).max() <= 1 and lsb(results['b16'], want['bf16']).max() <= 6
+    assert lsb(results['b32'], want['fp32']).max() <= 1 and lsb(results['b16'], want['bf16']).max() <= BF16_TOL
     assert lsb(results['s0'], want['fp32'][0]).max() <= 1 and lsb(results['s5'], want['fp32'][5]).max() <= 1
 
 
@@ -392,7 +398,7 @@ def test_batches_far_beyond_the_bench_size(random_model, precision, B, T):
         chunk = np.ascontiguousarray(base[:, c * T * 256:(c + 1) * T * 256])
         y = kb.process(np.tile(chunk, (reps, 1))[:B])
         want = ref.process(chunk)
-        assert lsb(y[:64], want).max() <= (6 if precision == 'bf16' else 1)
+        assert lsb(y[:64], want).max() <= (BF16_TOL if precision == 'bf16' else 1)
         full = (B // 64) * 64
         assert np.array_equal(y[:full].reshape(B // 64, 64, -1), np.broadcast_to(y[:64], (B // 64, 64, y.shape[1])))
         if B > full:
@@ -473,7 +479,7 @@ def test_dispatch_boundaries(random_model, precision, B, T):
     x = np.tile(base, ((B + 127) // 128, 1))[:B]
     kb = koala_amd.create_batch('key', B, T, precision, model_path=random_model)
     ref = oracle.Oracle(random_model, 128, oracle.PREC_BF16 if precision == 'bf16' else oracle.PREC_FP32)
-    tol = 6 if precision == 'bf16' else 1
+    tol = BF16_TOL if precision == 'bf16' else 1
     for c in range(2):
         y = kb.process(np.ascontiguousarray(x[:, c * T * 256:(c + 1) * T * 256]))
         want = ref.process(np.ascontiguousarray(base[:, c * T * 256:(c + 1) * T * 256]))
