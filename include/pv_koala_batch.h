@@ -36,7 +36,8 @@ PV_API void pv_koala_batch_delete(pv_koala_batch_t *object);
  * (kernels are enqueued on the handle's stream and the call returns without synchronising). */
 PV_API pv_status_t pv_koala_batch_process(pv_koala_batch_t *object, const int16_t *pcm, int16_t *enhanced);
 
-/* `num_frames` consecutive frames per stream: [num_streams][num_frames*256]. */
+/* `num_frames` consecutive frames per stream: [num_streams][num_frames*256].  `enhanced` may be the same buffer as `pcm`
+ * (in-place); a partial overlap is handled like a full one. */
 PV_API pv_status_t pv_koala_batch_process_chunk(pv_koala_batch_t *object, int32_t num_frames, const int16_t *pcm,
                                                 int16_t *enhanced);
 

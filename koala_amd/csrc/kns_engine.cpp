@@ -483,7 +483,7 @@ bool Engine::reset(const uint8_t *host_mask, std::string *err) {
     return true;
 }
 
-bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string *err) {
+bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string *err, bool allow_recompute) {
     const int mtb = Bpad_ / 16;
     const int M = mtb * T;
     last_T_ = T;
@@ -509,7 +509,9 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     // The spectrum makes its round trip through HBM only where it has to: in single-frame calls (the history is updated in
     // place there, so the synthesis kernel cannot rebuild it) and when the debug taps are on.  Otherwise the synthesis
     // kernel recomputes it from the PCM.
-    const bool recompute = !in_place && !no_recompute_;
+    // (a caller whose `enhanced` overlaps its `pcm` gets the stored-spectrum form: the synthesis kernel would otherwise
+    // read input frames it has already overwritten)
+    const bool recompute = !in_place && !no_recompute_ && allow_recompute;
     an.write_spec = !recompute || debug_taps_;
     {   // time segments: about four workgroups per CU
         int seg = T;
@@ -770,7 +772,11 @@ bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err, 
         *err = "`pcm` and `enhanced` must both be host or both be device memory.";
         return false;
     }
-    if (kin == kPtrDevice) return run_device(T, pcm, out, err);
+    if (kin == kPtrDevice) {
+        const size_t n = (size_t) B_ * T * kFrame;
+        const bool overlap = pcm < out + n && out < pcm + n;
+        return run_device(T, pcm, out, err, !overlap);
+    }
     if (T > host_chunk_ && bytes >= host_pipeline_min_bytes_)
         return process_host_pipelined(T, pcm, out, kin == kPtrPinned && kout == kPtrPinned, err);
     memcpy(h_in_, pcm, bytes);

@@ -53,7 +53,7 @@ public:
 private:
     Engine() {}
     bool init(const Params &p, int device, int B, int Tmax, int precision, std::string *err, bool *oom);
-    bool run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string *err);
+    bool run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string *err, bool allow_recompute = true);
     void *dalloc(size_t bytes, bool zero);
     void *upload(const void *src, size_t bytes);
     void tick(int cls);

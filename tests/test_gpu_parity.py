@@ -148,6 +148,26 @@ def test_device_pointers_on_caller_stream(random_model):
     kb.delete()
 
 
+def test_device_call_in_place(random_model):
+    """`enhanced` == `pcm` for a multi-frame device-pointer call: the synthesis kernel rebuilds spectra from the input, so the
+    engine must notice the overlap and keep the spectrum instead; the samples equal those of a call with separate buffers."""
+    torch = pytest.importorskip('torch')
+    x = synth_streams(40, 12, seed=14)
+    for precision in ('fp32', 'bf16'):
+        kb = koala_amd.create_batch('key', 40, 6, precision, model_path=random_model)
+        want = np.concatenate([kb.process(np.ascontiguousarray(x[:, c * 1536:(c + 1) * 1536])) for c in range(2)], axis=1)
+        kb.reset()
+        got = []
+        for c in range(2):
+            d = torch.from_numpy(np.ascontiguousarray(x[:, c * 1536:(c + 1) * 1536])).cuda()
+            torch.cuda.synchronize()
+            kb.process_device(6, d.data_ptr(), d.data_ptr())
+            kb.synchronize()
+            got.append(d.cpu().numpy())
+        kb.delete()
+        assert np.array_equal(np.concatenate(got, axis=1), want)
+
+
 @pytest.mark.parametrize('B,Tmax,T,chunk', [(33, 32, 32, '16'), (33, 32, 21, '16'), (20, 8, 7, '4'), (48, 16, 16, '3'),
                                             (16, 32, 32, '0'), (5, 2, 2, '1')])
 def test_host_pointer_calls_are_pipelined_without_changing_results(random_model, monkeypatch, B, Tmax, T, chunk):
