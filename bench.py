@@ -384,6 +384,21 @@ def main():
         cpu['gpu_vs_oracle_max_lsb'] = parity['max_lsb']
     if rank == 0 and world == 1 and not args.no_extra:
         extra = extra_points(args, torch, np, koala_amd, model, kb, x, dx, dy, base, local_rank)
+    # the constants the fractions are divided by, next to what a plain device-to-device copy reaches on this box
+    peaks = {'hbm_GBps': HBM_PEAK_GBS, 'mfma_TFLOPs': MFMA_PEAK_TFLOPS[args.precision]}
+    if rank == 0:
+        src = torch.empty(1 << 30, dtype=torch.uint8, device='cuda')
+        dst = torch.empty_like(src)
+        src.fill_(1)
+        for _ in range(3):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        for _ in range(20):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+        peaks['measured_d2d_copy_GBps'] = round(2.0 * src.numel() * 20 / (time.perf_counter() - c0) / 1e9, 1)
+        del src, dst
 
     kb.delete()
     if world > 1:
@@ -414,6 +429,7 @@ def main():
         'real_time_factor': round(elapsed_max / (args.steps * T * 256 / 16000.0) / B, 9),
         'frames_per_sec_per_gpu': round(value / world, 1),
         'roofline': roofline,
+        'peaks': peaks,
         'stages': stages,
         'cpu_baseline': cpu,
         'parity': parity,

@@ -514,9 +514,10 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     const bool recompute = !in_place && !no_recompute_ && allow_recompute;
     an.write_spec = !recompute || debug_taps_;
     {   // time segments: about four workgroups per CU
+        static const int seg_env = getenv("KOALA_AMD_ANALYSIS_SEG") ? atoi(getenv("KOALA_AMD_ANALYSIS_SEG")) : 0;  // tuning switch
         int seg = T;
         while (seg > 4 && (Bpad_ / 16) * ((T + seg - 1) / seg) < 1024) seg = (seg + 1) / 2;
-        an.seg = seg;
+        an.seg = seg_env > 0 ? (seg_env < T ? seg_env : T) : seg;
     }
     const int16_t *hist_before = d_hist_[hist_cur_];
     // developer switch (power / clock probing, results are garbage): launch only the kernels of one class
