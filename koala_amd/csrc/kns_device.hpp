@@ -291,14 +291,8 @@ __device__ __forceinline__ void fft_partner(const cpx (&a)[16], cpx (&p)[16], in
     }
 }
 
-constexpr int kGruTilesPerWave = 5;  // 17 unit tiles over 4 waves: 5,4,4,4
-
-// ---- bf16 recurrent kernel with the layer's W_hh RESIDENT on the CU for all T steps ("persistent RNN"):
-// 459 KiB of B-fragments = 4 waves x 3 unit tiles x 27 blocks in VGPRs (324 registers per lane, one wave per SIMD with
-// the whole 512-register file) + 4 x 27 KiB + 27 KiB in LDS.  Per step a wave then needs only the 16 x 288 bf16 hidden
-// tile from LDS and its 15/12 pre-activation tiles from HBM: no weight traffic at all after the prologue.
-// Gate nonlinearities use the hardware transcendentals (v_exp_f32, v_rcp_f32): the bf16 configuration is specified to a
-// tolerance, not bit for bit.
+// ---- helpers of the weight-resident bf16 kernels.  Gate nonlinearities use the hardware transcendentals (v_exp_f32,
+// v_rcp_f32): the bf16 configuration is specified to a tolerance, not bit for bit.
 
 __device__ __forceinline__ float fast_sigmoid(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
@@ -315,35 +309,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.88539008177792681f));
 }
 
-constexpr int kResTileBytes = 3 * PBF16::NBH * 1024;  // one unit tile of W_hh: 3 gates x 9 k-blocks x 1 KiB
 constexpr int kResBiasBytes = kGateTiles * 16 * 4;
-constexpr int kResLds = 2 * PBF16::NBH * 1024 + 5 * kResTileBytes + kResBiasBytes;  // h double buffer, 4 + 1 tiles, b_hh
-
-// hipcc keeps values it loaded itself in VGPRs and reaches the accumulator half of the register file only through
-// v_accvgpr copies.  Passing a fragment once through an "a"-constrained empty asm re-defines it as an AGPR value; the
-// MFMA builtins then take it as an AGPR source operand directly, so 216 registers of weights cost no VGPR and no copy.
-__device__ __forceinline__ bf16x8 pin_to_agpr(bf16x8 w) {
-    asm volatile("" : "+a"(w));
-    return w;
-}
-
-// acc[gt] += a[blk] . W for one LDS-resident unit tile stored as [k-block][gate][lane]; the explicit queue keeps
-// kQueue ds_read_b128 in flight so that LDS latency is not paid per MFMA
-template <int NBH, int kQueue>
-__device__ __forceinline__ void mma_lds_tile(f32x4 (&acc)[3], const bf16x8 (&a)[NBH], const bf16x8 *wl, int lane) {
-    constexpr int N = 3 * NBH;
-    bf16x8 qb[kQueue];
-#pragma unroll
-    for (int p = 0; p < kQueue; ++p) qb[p] = wl[p * 64 + lane];
-    __builtin_amdgcn_sched_barrier(0);  // pin the order: without it hipcc sinks each read next to its MFMA
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const bf16x8 b = qb[i % kQueue];
-        if (i + kQueue < N) qb[i % kQueue] = wl[(i + kQueue) * 64 + lane];
-        acc[i % 3] = PBF16::mma(a[i / 3], b, acc[i % 3]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));

@@ -124,137 +124,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 }
 
-// ---- weight-stationary form of the GRU input-side GEMM (bf16):  Gi = [y_prev ; e] . W_ih + b_ih  over ALL stream-frames.
-// The 51 x 9 e-part blocks of W_ih stay on the CU exactly as W_hh does in gru_resident_kernel (VGPR / AGPR / LDS per
-// wave); the y_prev part (0..2 k-blocks) is re-read from L2 per m-tile.  A persistent workgroup walks over m-tiles:
-// A fragments come straight from HBM in fragment order (no LDS, no barrier), C tiles leave as fp16 fragments.
-// HBM traffic per m-tile is the algorithmic minimum: 9-11 KiB in, 25.5 KiB out.
-constexpr int kWsABlocks = PBF16::NBH + 2;                               // k-blocks of one A tile (y part <= 2)
-constexpr int kWsLds = 5 * kResTileBytes + 2 * kWsABlocks * 1024;        // weight tiles 3, 4 + A double buffer
-
-template <int NB0>
-__global__ __launch_bounds__(256, 1) void gemm_ws_kernel(GemmArgs g) {
-    typedef PBF16 P;
-    typedef P::frag_t frag_t;
-    constexpr int NBH = P::NBH;
-    __shared__ __attribute__((aligned(16))) char smem[kWsLds];
-    frag_t *abuf = (frag_t *) (smem + 5 * kResTileBytes);  // [2][kWsABlocks][64]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int colq = lane & 15;
-    constexpr int nb0 = NB0, nb = NB0 + NBH;
-    const frag_t *w = (const frag_t *) g.w;
-
-    frag_t wv[3][NBH];
-    frag_t wa[2][3][NBH];
-#pragma unroll
-    for (int gt = 0; gt < 3; ++gt)
-#pragma unroll
-        for (int blk = 0; blk < NBH; ++blk) wv[gt][blk] = w[((size_t) (wave * 3 + gt) * nb + nb0 + blk) * 64 + lane];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int gt = 0; gt < 3; ++gt)
-#pragma unroll
-            for (int blk = 0; blk < NBH; ++blk) {
-                wa[q][gt][blk] = pin_to_agpr(w[((size_t) ((wave + 4 * (q + 1)) * 3 + gt) * nb + nb0 + blk) * 64 + lane]);
-            }
-    frag_t *wl3 = (frag_t *) (smem + wave * kResTileBytes);
-    frag_t *wl4 = (frag_t *) (smem + 4 * kResTileBytes);
-    for (int gt = 0; gt < 3; ++gt)
-        for (int blk = 0; blk < NBH; ++blk)
-            wl3[(blk * 3 + gt) * 64 + lane] = w[((size_t) ((wave + 12) * 3 + gt) * nb + nb0 + blk) * 64 + lane];
-    if (wave == 0)
-        for (int gt = 0; gt < 3; ++gt)
-            for (int blk = 0; blk < NBH; ++blk)
-                wl4[(blk * 3 + gt) * 64 + lane] = w[((size_t) (16 * 3 + gt) * nb + nb0 + blk) * 64 + lane];
-    float bias[kGruTilesPerWave][3];
-#pragma unroll
-    for (int q = 0; q < kGruTilesPerWave; ++q)
-#pragma unroll
-        for (int gt = 0; gt < 3; ++gt) {
-            const int u = wave + 4 * q;
-            bias[q][gt] = u < kUnitTiles ? g.bias[(u * 3 + gt) * 16 + colq] : 0.0f;
-        }
-
-    // A tile staging: block j of an m-tile (j < nb0: y part, else e part) is fetched by wave j & 3
-    const frag_t *a0p = (const frag_t *) g.a0;
-    const frag_t *a1p = (const frag_t *) g.a1;
-    auto fetch = [&](int mtile, int j) -> frag_t {
-        return j < nb0 ? a0p[((size_t) mtile * nb0 + j) * 64 + lane] : a1p[((size_t) mtile * NBH + (j - nb0)) * 64 + lane];
-    };
-    int mt = blockIdx.x;
-    if (mt < g.mtiles)
-        for (int j = wave; j < nb; j += 4) abuf[j * 64 + lane] = fetch(mt, j);
-    __syncthreads();
-
-    int cur = 0;
-    for (; mt < g.mtiles; mt += gridDim.x) {
-        const int mn = mt + gridDim.x;
-        frag_t stage[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int j = wave + 4 * i;
-            if (mn < g.mtiles && j < nb) stage[i] = fetch(mn, j);  // in flight during this tile's MFMAs
-        }
-        const frag_t *ab = abuf + cur * kWsABlocks * 64;
-        frag_t cy[NB0 > 0 ? NB0 : 1], ce[NBH];
-#pragma unroll
-        for (int blk = 0; blk < NB0; ++blk) cy[blk] = ab[blk * 64 + lane];
-#pragma unroll
-        for (int blk = 0; blk < NBH; ++blk) ce[blk] = ab[(nb0 + blk) * 64 + lane];
-        P::gi_t *out = (P::gi_t *) g.out + (size_t) mt * kGateTiles * 64;
-#pragma unroll
-        for (int q = 0; q < kGruTilesPerWave; ++q) {
-            const int u = wave + 4 * q;
-            {
-                f32x4 acc[3];
-#pragma unroll
-                for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (NB0 > 0) {
-                    frag_t wy[NB0 > 0 ? NB0 : 1][3];
-                    __builtin_amdgcn_sched_barrier(0);  // keep the streamed y-part loads of other tiles out of here
-#pragma unroll
-                    for (int blk = 0; blk < NB0; ++blk)
-#pragma unroll
-                        for (int gt = 0; gt < 3; ++gt)
-                            wy[blk][gt] = w[((size_t) ((u < kUnitTiles ? u : 0) * 3 + gt) * nb + blk) * 64 + lane];
-#pragma unroll
-                    for (int blk = 0; blk < NB0; ++blk)
-#pragma unroll
-                        for (int gt = 0; gt < 3; ++gt) acc[gt] = P::mma(cy[blk], wy[blk][gt], acc[gt]);
-                }
-                if (q < 3) {
-#pragma unroll
-                    for (int blk = 0; blk < NBH; ++blk)
-#pragma unroll
-                        for (int gt = 0; gt < 3; ++gt)
-                            acc[gt] = P::mma(ce[blk], q == 0 ? wv[gt][blk] : wa[q == 2 ? 1 : 0][gt][blk], acc[gt]);
-                } else {
-                    mma_lds_tile<NBH, 4>(acc, ce, q == 3 ? wl3 : wl4, lane);
-                }
-#pragma unroll
-                for (int gt = 0; gt < 3; ++gt) {
-                    f32x4 v = acc[gt];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[q][gt];
-                    if (q < 4 || wave == 0) out[(u * 3 + gt) * 64 + lane] = P::to_gi(v);
-                }
-            }
-        }
-        frag_t *an = abuf + (cur ^ 1) * kWsABlocks * 64;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int j = wave + 4 * i;
-            if (mn < g.mtiles && j < nb) an[j * 64 + lane] = stage[i];
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-}
-
-// ---- second form of the weight-stationary input GEMM: the 51 n-tiles are split over a PAIR of workgroups that sit on
+// ---- weight-stationary form of the GRU input-side GEMM (bf16):  Gi = [y_prev ; e] . W_ih + b_ih  over ALL stream-frames: the 51 n-tiles are split over a PAIR of workgroups that sit on
 // the same XCD (blocks g and g + 8), so one wave keeps at most 7 n-tiles x (9 + NB0) k-blocks = 77 fragments -- all of
 // them in registers (3 n-tiles in VGPRs, 4 pinned in AGPRs), including the y_prev part.  No weight ever comes from LDS
 // or L2 inside the loop; LDS only double-buffers A tiles, kWs2Stage m-tiles per barrier.  The partner's second read of
@@ -647,29 +517,34 @@ void launch_gemm(const GemmArgs &a, hipStream_t s) {
     static const bool no_ws = getenv("KOALA_AMD_GEMM_GENERIC") != nullptr;  // A/B switch for profiling
     if (a.precision == kBf16 && a.out_kind == kOutGi && a.ntiles == kGateTiles && a.nb1 == PBF16::NBH && a.nb0 <= 2 &&
         a.mtiles >= 256 && !no_ws) {
-        static const bool ws1 = getenv("KOALA_AMD_GEMM_WS1") != nullptr;  // A/B switch: first weight-stationary form
+        // The weight-stationary kernel splits the m-tiles over 256 workgroup pairs: it takes the largest multiple of 256,
+        // the remaining < 256 m-tiles (ragged stream counts) go through the generic kernel -- the same arithmetic, bit
+        // for bit (tests/test_gpu_parity.py::test_alternative_kernels_give_identical_pcm).
+        GemmArgs m = a;
+        m.mtiles = a.mtiles / 256 * 256;
         const dim3 grid(256), block(64 * kWs2Waves);
-        if (ws1 || a.mtiles % 256 != 0) {
-            if (a.nb0 == 0)
-                hipLaunchKernelGGL(gemm_ws_kernel<0>, dim3(256), dim3(256), 0, s, a);
-            else if (a.nb0 == 1)
-                hipLaunchKernelGGL(gemm_ws_kernel<1>, dim3(256), dim3(256), 0, s, a);
-            else
-                hipLaunchKernelGGL(gemm_ws_kernel<2>, dim3(256), dim3(256), 0, s, a);
-        } else if (a.mtiles % 512 == 0) {  // four m-tiles per barrier
+        if (m.mtiles % 512 == 0) {  // four m-tiles per barrier
             if (a.nb0 == 0)  // (eight per barrier measured the same)
-                hipLaunchKernelGGL((gemm_ws2_kernel<0, 4>), grid, block, 0, s, a);
+                hipLaunchKernelGGL((gemm_ws2_kernel<0, 4>), grid, block, 0, s, m);
             else if (a.nb0 == 1)
-                hipLaunchKernelGGL((gemm_ws2_kernel<1, 4>), grid, block, 0, s, a);
+                hipLaunchKernelGGL((gemm_ws2_kernel<1, 4>), grid, block, 0, s, m);
             else
-                hipLaunchKernelGGL((gemm_ws2_kernel<2, 4>), grid, block, 0, s, a);
+                hipLaunchKernelGGL((gemm_ws2_kernel<2, 4>), grid, block, 0, s, m);
         } else {
             if (a.nb0 == 0)
-                hipLaunchKernelGGL((gemm_ws2_kernel<0, 2>), grid, block, 0, s, a);
+                hipLaunchKernelGGL((gemm_ws2_kernel<0, 2>), grid, block, 0, s, m);
             else if (a.nb0 == 1)
-                hipLaunchKernelGGL((gemm_ws2_kernel<1, 2>), grid, block, 0, s, a);
+                hipLaunchKernelGGL((gemm_ws2_kernel<1, 2>), grid, block, 0, s, m);
             else
-                hipLaunchKernelGGL((gemm_ws2_kernel<2, 2>), grid, block, 0, s, a);
+                hipLaunchKernelGGL((gemm_ws2_kernel<2, 2>), grid, block, 0, s, m);
+        }
+        if (a.mtiles > m.mtiles) {
+            GemmArgs t = a;
+            t.mtiles = a.mtiles - m.mtiles;
+            if (a.a0) t.a0 = (const char *) a.a0 + (size_t) m.mtiles * a.nb0 * 1024;
+            t.a1 = (const char *) a.a1 + (size_t) m.mtiles * a.nb1 * 1024;
+            t.out = (char *) a.out + (size_t) m.mtiles * kGateTiles * 64 * sizeof(PBF16::gi_t);
+            launch_gemm_p<PBF16>(t, s);
         }
         return;
     }

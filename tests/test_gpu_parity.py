@@ -295,14 +295,14 @@ print('DIGEST', h.hexdigest())
 
 def test_alternative_kernels_give_identical_pcm(random_model):
     """Every A/B switch selects other kernels for the same arithmetic (weight-streaming vs resident recurrent kernels, the
-    one- and two-wave-per-SIMD forms, generic vs weight-stationary GEMMs, ...): the PCM must not change by a bit."""
+    generic vs weight-stationary GEMMs, stored vs recomputed spectrum, ...): the PCM must not change by a bit."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = _SWITCH_SCRIPT % {'root': root, 'tests': os.path.join(root, 'tests'), 'model': random_model}
     digests = {}
-    for switch in ('', 'KOALA_AMD_GRU_STREAM', 'KOALA_AMD_GEMM_GENERIC', 'KOALA_AMD_GEMM_WS1',
+    for switch in ('', 'KOALA_AMD_GRU_STREAM', 'KOALA_AMD_GEMM_GENERIC',
                    'KOALA_AMD_GEMM_NO_WSR', 'KOALA_AMD_NO_SMALL', 'KOALA_AMD_NO_GRAPH', 'KOALA_AMD_STORE_SPECTRUM',
                    'KOALA_AMD_DEBUG_TAPS'):
         env = dict(os.environ)
