@@ -562,8 +562,14 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         tock(kClsGru);
     };
 
-    // one frame of a few m-tiles: latency matters, not throughput -- whole GRU layers as single wide launches
-    const bool small = T == 1 && mtb <= 16 && !no_small_;
+    // One frame per call: whole GRU layers (input GEMM + recurrent GEMM + gates) as single wide launches of the low-latency
+    // kernel -- 17 x mtb workgroups that stream their share of both weight matrices from L2, no pre-activation round trip,
+    // half the launches.  The weight-resident kernels first pull 459 KiB per CU for ONE step, so the fused form wins up to
+    // 192 m-tiles in bf16 (3 072 streams: 218 vs 264 us per frame step; 512 streams: 113 vs 212; at 4 096 it loses, 256 vs
+    // 222) and at every size measured in fp32 (4 096 streams: 628 vs 815 us).  Same arithmetic, bit for bit.
+    static const int small_env = getenv("KOALA_AMD_SMALL_MT") ? atoi(getenv("KOALA_AMD_SMALL_MT")) : 0;  // tuning switch
+    const int small_mt = small_env > 0 ? small_env : (prec_ == kBf16 ? 192 : 256);
+    const bool small = T == 1 && mtb <= small_mt && !no_small_;
     // Fewer than 256 m-tiles: the chunked recurrent kernels would occupy mtb workgroups, so the layers run frame
     // by frame through the low-latency kernel instead (17 x mtb workgroups of three waves per frame, input GEMM included):
     // in fp32 at 256 streams x 32 frames 8 x 32 launches of ~13 us beat 8 x (0.1 + 0.75) ms (2.8 vs 1.2 M frames/s; 5.5 vs

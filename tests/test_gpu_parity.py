@@ -490,11 +490,12 @@ def test_baseline_config1_b256_fp32_at_its_stated_size(random_model, T, calls):
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
-@pytest.mark.parametrize('B,T', [(256, 1), (272, 1), (3072, 2), (3088, 2)])
+@pytest.mark.parametrize('B,T', [(256, 1), (272, 1), (3072, 1), (3088, 1), (4096, 1), (4112, 1), (3072, 2), (3088, 2)])
 def test_dispatch_boundaries(random_model, precision, B, T):
-    """The engine switches kernel families at 16 -> 17 m-tiles (one frame: low-latency layer kernel vs input GEMM +
-    recurrent kernel) and at 192 -> 193 m-tiles (fp32, several frames: frame-by-frame layers vs chunked recurrence),
-    kns_engine.cpp run_device().  Both sides of both edges, two calls each, every stream against the oracle."""
+    """The engine switches kernel families between one-frame calls below and above 192 m-tiles (bf16) / 256 m-tiles (fp32)
+    (low-latency layer kernel vs input GEMM + recurrent kernel; 16 m-tiles was the edge in round 1) and at 192 -> 193
+    m-tiles for several frames in fp32 (frame-by-frame layers vs chunked recurrence), kns_engine.cpp run_device().  Both
+    sides of every edge, two calls each, every stream against the oracle."""
     base = synth_streams(128, 2 * T, seed=B)
     x = np.tile(base, ((B + 127) // 128, 1))[:B]
     kb = koala_amd.create_batch('key', B, T, precision, model_path=random_model)
