@@ -40,12 +40,9 @@ MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}  # dense peaks, no sparsity
 H = 271
 G3 = 813
 HEADS = (1, 5, 40, 257)
-# algorithmic work per stream-frame (unpadded dims).  STFT stages, SURVEY.md 8d dataflow (spectrum stored as fp32 and read
-# back, fp32 features, history / tail through HBM every frame) ...
-SURVEY_BYTES_ANALYSIS = 512 + 512 + 512 + 2056 + 1028
-SURVEY_BYTES_SYNTHESIS = 2056 + 1028 + 1024 + 1024 + 512
-# ... and the dataflow of this engine since round 2: no stored spectrum in multi-frame calls (the
-# synthesis kernel rebuilds it from the PCM), operand-typed features, history and overlap-add tail stay on chip inside a call
+# algorithmic work per stream-frame (unpadded dims).  STFT stages: the dataflow of this engine since round 2 (DESIGN.md
+# section 6; SURVEY.md 8d priced a dataflow that stored the spectrum: 4 620 / 5 644 B): no stored spectrum in multi-frame calls
+# (the synthesis kernel rebuilds it from the PCM), operand-typed features, history and overlap-add tail stay on chip inside a call
 BYTES_ANALYSIS = {'bf16': 512 + 257 * 2, 'fp32': 512 + 257 * 4}      # PCM in, features out
 BYTES_SYNTHESIS = 512 + 257 * 4 + 512                                # PCM in, fp32 mask in, PCM out
 MAC_GEMM_IN = (271 + 272 + 276 + 311 + 4 * 271) * G3      # 8 input-side GEMMs (W_ih)
@@ -103,6 +100,63 @@ def launch_ranks(args):
         p.kill()
         rc = rc or 124
     return rc
+
+
+class BoardSampler(object):
+    """sclk and board power of one GPU from amdgpu's sysfs files while the timed region runs (a host thread reading two
+    small files every 50 ms; nothing is launched on the GPU).  Every field is None where the files do not exist."""
+    PEAK_SCLK_MHZ = 2400.0  # MI355X peak engine clock: what the 2.5 PFLOP/s dense bf16 figure is quoted at
+
+    def __init__(self, index):
+        import glob
+        import threading
+        self.samples = []
+        self._stop = threading.Event()
+        self._sclk, self._power = None, None
+        cards = sorted(glob.glob('/sys/class/drm/card[0-9]*/device/pp_dpm_sclk'))
+        if index < len(cards):
+            self._sclk = cards[index]
+            hw = sorted(glob.glob(os.path.join(os.path.dirname(cards[index]), 'hwmon', 'hwmon*', 'power1_average')) +
+                        glob.glob(os.path.join(os.path.dirname(cards[index]), 'hwmon', 'hwmon*', 'power1_input')))
+            self._power = hw[0] if hw else None
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        mhz, watts = None, None
+        try:
+            for ln in open(self._sclk):
+                if '*' in ln:
+                    mhz = float(ln.split(':')[1].strip().split('M')[0])
+        except Exception:
+            pass
+        try:
+            watts = float(open(self._power).read()) / 1e6
+        except Exception:
+            pass
+        return mhz, watts
+
+    def _run(self):
+        while not self._stop.is_set():
+            self.samples.append(self._read())
+            self._stop.wait(0.05)
+
+    def __enter__(self):
+        if self._sclk:
+            self._thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self._sclk:
+            self._thread.join()
+
+    def summary(self):
+        import statistics
+        mhz = [m for m, _ in self.samples if m]
+        w = [p for _, p in self.samples if p]
+        return {'sclk_MHz_median': statistics.median(mhz) if mhz else None, 'sclk_MHz_min': min(mhz) if mhz else None,
+                'board_power_W_mean': round(sum(w) / len(w), 1) if w else None, 'samples': len(self.samples),
+                'peak_sclk_MHz': self.PEAK_SCLK_MHZ, 'source': 'amdgpu sysfs pp_dpm_sclk / hwmon power1_average'}
 
 
 def time_steps(fn, sync, steps, warmup):
@@ -187,6 +241,38 @@ def extra_points(args, torch, np, koala_amd, model, kb, x, dx, dy, base, local_r
             'frames_per_s': round(1.0 / float(np.mean(lat)), 1),
             'real_time_factor': round(float(np.mean(lat)) / 0.016, 5)}
     os.environ.pop('KOALA_AMD_PRECISION', None)
+
+    # -- BASELINE configs[0], the one number the reference publishes a bound for: seconds to push the 365 full frames of
+    # resources/audio_samples/test.wav through Koala.process() (binding/python/test_koala_perf.py:42-58: mean of the timed
+    # iterations after warm-up; CI ceiling 0.8 s on cpu:1, .github/workflows/python-perf.yml:45-53).  Here on gpu:N with the
+    # default model: one pv_koala_process call (hipGraph replay) per frame.
+    try:
+        import wave
+        with wave.open(os.path.join(ROOT, 'tests', 'golden', 'test.wav'), 'rb') as f:
+            wav = np.frombuffer(f.readframes(f.getnframes()), dtype=np.int16)
+        nf = len(wav) // 256
+        frames = [wav[i * 256:(i + 1) * 256] for i in range(nf)]
+        res = {}
+        for prec in ('fp32', 'bf16'):
+            os.environ['KOALA_AMD_PRECISION'] = prec
+            k = koala_amd.create('bench', device=dev, library_path=args.library)
+            secs = []
+            for it in range(21):
+                t0 = time.perf_counter()
+                for fr in frames:
+                    k.process(fr)
+                if it:  # iteration 0 is the warm-up
+                    secs.append(time.perf_counter() - t0)
+            k.delete()
+            res[prec] = round(float(np.mean(secs)), 5)
+        os.environ.pop('KOALA_AMD_PRECISION', None)
+        out['config0_testwav_loop'] = {
+            'workload': 'BASELINE configs[0] loop: %d frames of tests/golden/test.wav through Koala.process(), one frame per '
+                        'call, mean of 20 iterations after 1 warm-up, device %s, default model' % (nf, dev),
+            'seconds_fp32': res['fp32'], 'seconds_bf16': res['bf16'], 'reference_ci_ceiling_seconds_cpu1': 0.8,
+            'frames_per_s_fp32': round(nf / res['fp32'], 1), 'real_time_factor_fp32': round(res['fp32'] / (nf * 0.016), 5)}
+    except Exception as e:  # the fixture travels with the repository; never fail the bench line over an extra
+        out['config0_testwav_loop'] = {'error': repr(e)}
     return out
 
 
@@ -261,6 +347,8 @@ def main():
     step()
     torch.cuda.synchronize()
     first_call = dy[:distinct].cpu().numpy() if (rank == 0 and world == 1) else None
+    # ... and its masks (the mask head's output buffer, read back through the debug tap; only the parity leg uses them)
+    first_mask = kb.debug_read('mask', T)[:, :distinct] if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
 
     t_prime = time.perf_counter()
     while time.perf_counter() - t_prime < args.prime_seconds:  # clock ramp, untimed (see --prime-seconds)
@@ -269,11 +357,13 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    with BoardSampler(local_rank) as board:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    board = board.summary()
     frames_total, elapsed_max = aggregate_throughput(B * T * args.steps, elapsed)
     value = frames_total / elapsed_max
 
@@ -311,11 +401,12 @@ def main():
                         'frac': round(achieved / peak, 5), 'avg_launch_ms': round(ms, 5),
                         'launches_per_step': round(actual, 2) if actual != int(actual) else int(actual),
                         'share_of_device_time': round(ms * actual / dev_ms, 4) if dev_ms else None}
+        if bound == 'mfma' and board.get('sclk_MHz_median'):
+            # the same fraction against the matrix peak AT THE CLOCK THE BOARD SUSTAINED under its power cap in the timed region
+            stages[name]['frac_at_sustained_sclk'] = round(achieved / (peak * board['sclk_MHz_median'] / board['peak_sclk_MHz']), 5)
         if name in ('analysis', 'synthesis'):
-            # these two are limited by VALU issue, not by HBM: `frac` prices the bytes the dataflow
-            # needs; the round-1 figure (SURVEY's dataflow, which stored the spectrum) is kept for comparison
-            sv = (SURVEY_BYTES_ANALYSIS if name == 'analysis' else SURVEY_BYTES_SYNTHESIS) * frames_per_launch
-            stages[name]['frac_by_survey_dataflow_bytes'] = round(sv / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            # limited by VALU issue, not by HBM: `frac` prices the bytes the dataflow needs, and
+            # `frac_of_peak_by_traffic` (below) the bytes the kernel was measured to move
             stages[name]['limited_by'] = 'VALU issue'
 
     dominant = max(stages, key=lambda k: stages[k]['avg_launch_ms'] * stages[k]['launches_per_step'])
@@ -367,7 +458,15 @@ def main():
         c0 = time.perf_counter()
         o.process(xs)
         dt = time.perf_counter() - c0
+        # one thread, for scale: the multi-thread figure is a weak baseline (shared weights, 64-stream blocks per thread)
+        n1 = 64
+        o1 = oracle.Oracle(model, n1, oracle.PREC_FP32)
+        x1 = np.ascontiguousarray(np.tile(base, ((n1 + distinct - 1) // distinct, 1))[:n1, :16 * 256])
+        c1 = time.perf_counter()
+        o1.process(x1, 1)
+        rate1 = n1 * 16 / (time.perf_counter() - c1)
         cpu = {'value': round(ns * T / dt, 1), 'unit': 'frames/s', 'cores': ncores, 'kind': 'port',
+               'one_thread_frames_per_s': round(rate1, 1), 'scaling_vs_1_thread': round(ns * T / dt / rate1, 1),
                'sample': '%d streams x %d frames of the same synthetic workload, oracle/kns_oracle.c fp32 (register-blocked '
                          'k-ascending fmaf GEMMs, OpenMP over stream blocks of %d), %.1f s'
                          % (ns, T, oracle.block_size(), dt),
@@ -382,10 +481,17 @@ def main():
                   'max_lsb': int(d.max()), 'abs_diff_histogram_0_to_8plus': hist.tolist(),
                   'within_1_lsb': round(float((d <= 1).mean()), 6)}
         cpu['gpu_vs_oracle_max_lsb'] = parity['max_lsb']
+        # north_star's criterion for the floating-point mask path: the timed engine's masks against the UNROUNDED (fp32)
+        # oracle, RMS over every distinct stream x frame x bin of the batch
+        _, want_mask = oracle.Oracle(model, distinct, oracle.PREC_FP32).process_with_mask(np.ascontiguousarray(x[:distinct]))
+        dm = first_mask.astype(np.float64) - want_mask
+        parity['mask_rms_vs_fp32_oracle'] = float('%.3e' % np.sqrt(np.mean(dm * dm)))
+        parity['mask_max_abs_vs_fp32_oracle'] = float('%.3e' % np.abs(dm).max())
+        parity['mask_rms_bar'] = 1e-3
     if rank == 0 and world == 1 and not args.no_extra:
         extra = extra_points(args, torch, np, koala_amd, model, kb, x, dx, dy, base, local_rank)
     # the constants the fractions are divided by, next to what a plain device-to-device copy reaches on this box
-    peaks = {'hbm_GBps': HBM_PEAK_GBS, 'mfma_TFLOPs': MFMA_PEAK_TFLOPS[args.precision]}
+    peaks = {'hbm_GBps': HBM_PEAK_GBS, 'mfma_TFLOPs': MFMA_PEAK_TFLOPS[args.precision], 'board_during_timed_region': board}
     if rank == 0:
         src = torch.empty(1 << 30, dtype=torch.uint8, device='cuda')
         dst = torch.empty_like(src)

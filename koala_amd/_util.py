@@ -11,6 +11,12 @@ def default_library_path(relative: str = '') -> str:
     return os.path.join(_PKG, relative, 'lib', 'libpv_koala.so')
 
 
+def developer_library_path(relative: str = '') -> str:
+    """The -DKNS_DEV build of the same sources: kernel A/B selection, tuning knobs and the intermediate taps are steered
+    by environment variables there (tests/ and tools/ only; the product library reads none of them)."""
+    return os.path.join(_PKG, relative, 'lib', 'libpv_koala_dev.so')
+
+
 def default_model_path(relative: str = '') -> str:
     """The default parameter file written by `build_native()`: the hand-built spectral gate with an adaptive noise floor
     (params.make_adaptive_gate) -- nothing in it is derived from an audio file."""
@@ -19,7 +25,7 @@ def default_model_path(relative: str = '') -> str:
 
 def build_native(force: bool = False) -> str:
     """Compile koala_amd/lib/libpv_koala.so with hipcc for gfx950 (no GPU needed) and write the default model."""
-    lib = default_library_path()
+    lib, dev = default_library_path(), developer_library_path()
     src_dir = os.path.join(_PKG, 'csrc')
     deps = [os.path.join(src_dir, n) for n in os.listdir(src_dir)]
     deps += [os.path.join(_PKG, 'Makefile')]
@@ -28,7 +34,7 @@ def build_native(force: bool = False) -> str:
         deps += [os.path.join(inc, n) for n in os.listdir(inc)]
 
     def stale():
-        return not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps)
+        return any(not os.path.exists(l) or any(os.path.getmtime(d) > os.path.getmtime(l) for d in deps) for l in (lib, dev))
 
     if force or stale():
         # several ranks (torchrun) may get here at once: one builds, the others wait on the lock and find the result;
@@ -39,7 +45,7 @@ def build_native(force: bool = False) -> str:
             fcntl.flock(lock, fcntl.LOCK_EX)
             try:
                 if force or stale():
-                    subprocess.check_call(['make', '-C', _PKG, '-s'] + (['-B'] if force else []) + ['lib/libpv_koala.so'])
+                    subprocess.check_call(['make', '-C', _PKG, '-s'] + (['-B'] if force else []) + ['-j4', 'lib/libpv_koala.so', 'lib/libpv_koala_dev.so'])
             finally:
                 fcntl.flock(lock, fcntl.LOCK_UN)
     model = default_model_path()
@@ -52,4 +58,4 @@ def build_native(force: bool = False) -> str:
     return lib
 
 
-__all__ = ['default_library_path', 'default_model_path', 'build_native']
+__all__ = ['default_library_path', 'developer_library_path', 'default_model_path', 'build_native']

@@ -243,15 +243,27 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
         return false;
     }
     stream_ = own_stream_;
-    use_graph_ = getenv("KOALA_AMD_NO_GRAPH") == nullptr;
-    no_small_ = getenv("KOALA_AMD_NO_SMALL") != nullptr;          // developer switches, read once (not per frame)
-    no_zero_copy_ = getenv("KOALA_AMD_NO_ZERO_COPY") != nullptr;
-    no_recompute_ = getenv("KOALA_AMD_STORE_SPECTRUM") != nullptr;  // A/B switch: spectrum through HBM in every call
-    debug_taps_ = getenv("KOALA_AMD_DEBUG_TAPS") != nullptr;        // keep every intermediate debug_read() can return
+    // developer switches: read once per handle, and only in the -DKNS_DEV build (dev_env() is a constant nullptr otherwise)
+    use_graph_ = dev_env("KOALA_AMD_NO_GRAPH") == nullptr;
+    no_small_ = dev_env("KOALA_AMD_NO_SMALL") != nullptr;
+    no_zero_copy_ = dev_env("KOALA_AMD_NO_ZERO_COPY") != nullptr;
+    no_recompute_ = dev_env("KOALA_AMD_STORE_SPECTRUM") != nullptr;  // A/B switch: spectrum through HBM in every call
+    debug_taps_ = dev_env("KOALA_AMD_DEBUG_TAPS") != nullptr;        // keep every intermediate debug_read() can return
+    dev_variant_ = (dev_env("KOALA_AMD_GRU_STREAM") ? kDevGruStream : 0) | (dev_env("KOALA_AMD_GEMM_GENERIC") ? kDevGemmGeneric : 0) |
+                   (dev_env("KOALA_AMD_GEMM_NO_WSR") ? kDevGemmNoWsr : 0);
+    auto dev_int = [](const char *name, int dflt) {
+        const char *e = dev_env(name);
+        return e ? atoi(e) : dflt;
+    };
+    dev_only_class_ = dev_int("KOALA_AMD_ONLY_CLASS", -1);  // power / clock probing: launch one kernel class only (garbage out)
+    dev_analysis_seg_ = dev_int("KOALA_AMD_ANALYSIS_SEG", 0);
+    dev_synth_seg_ = dev_int("KOALA_AMD_SYNTH_SEG", 0);
+    dev_small_mt_ = dev_int("KOALA_AMD_SMALL_MT", 0);
+    dev_steps_mt_ = dev_int("KOALA_AMD_STEPS_MT", 192);
     // host-pointer calls are cut into sub-chunks of host_chunk_ frames (two staging slots = the Tmax-sized buffers)
     host_chunk_ = Tmax_ / 2 < 1 ? 1 : (Tmax_ / 2 > 16 ? 16 : Tmax_ / 2);
     host_pipeline_min_bytes_ = (size_t) 4 << 20;  // below this a call is launch-bound: sub-chunks would only add launches
-    if (const char *e = getenv("KOALA_AMD_HOST_CHUNK")) {  // developer/test switch: force a sub-chunk length; 0 = never split
+    if (const char *e = dev_env("KOALA_AMD_HOST_CHUNK")) {  // force a sub-chunk length; 0 = never split
         const int v = atoi(e);
         if (v >= 1 && v <= Tmax_ / 2) host_chunk_ = v, host_pipeline_min_bytes_ = 0;
         if (v == 0) host_chunk_ = Tmax_;
@@ -513,15 +525,15 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     // read input frames it has already overwritten)
     const bool recompute = !in_place && !no_recompute_ && allow_recompute;
     an.write_spec = !recompute || debug_taps_;
+    spec_valid_ = an.write_spec != 0;
     {   // time segments: about four workgroups per CU
-        static const int seg_env = getenv("KOALA_AMD_ANALYSIS_SEG") ? atoi(getenv("KOALA_AMD_ANALYSIS_SEG")) : 0;  // tuning switch
+        const int seg_env = dev_analysis_seg_;
         int seg = T;
         while (seg > 4 && (Bpad_ / 16) * ((T + seg - 1) / seg) < 1024) seg = (seg + 1) / 2;
         an.seg = seg_env > 0 ? (seg_env < T ? seg_env : T) : seg;
     }
     const int16_t *hist_before = d_hist_[hist_cur_];
-    // developer switch (power / clock probing, results are garbage): launch only the kernels of one class
-    static const int only = getenv("KOALA_AMD_ONLY_CLASS") ? atoi(getenv("KOALA_AMD_ONLY_CLASS")) : -1;
+    const int only = dev_only_class_;  // -1 in the product library
     tick(kClsAnalysis);
     if (only < 0 || only == kClsAnalysis) launch_analysis(an, stream_);
     tock(kClsAnalysis);
@@ -542,6 +554,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         g.n_valid = n_valid;
         g.out_kind = kind;
         g.precision = prec_;
+        g.dev = dev_variant_;
         tick(cls);
         if (only < 0 || only == cls) launch_gemm(g, stream_);
         tock(cls);
@@ -557,6 +570,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         g.T = T;
         g.mtiles = mtb;
         g.precision = prec_;
+        g.dev = dev_variant_;
         tick(kClsGru);
         if (only < 0 || only == kClsGru) launch_gru(g, stream_);
         tock(kClsGru);
@@ -567,7 +581,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     // half the launches.  The weight-resident kernels first pull 459 KiB per CU for ONE step, so the fused form wins up to
     // 192 m-tiles in bf16 (3 072 streams: 218 vs 264 us per frame step; 512 streams: 113 vs 212; at 4 096 it loses, 256 vs
     // 222) and at every size measured in fp32 (4 096 streams: 628 vs 815 us).  Same arithmetic, bit for bit.
-    static const int small_env = getenv("KOALA_AMD_SMALL_MT") ? atoi(getenv("KOALA_AMD_SMALL_MT")) : 0;  // tuning switch
+    const int small_env = dev_small_mt_;
     const int small_mt = small_env > 0 ? small_env : (prec_ == kBf16 ? 192 : 256);
     const bool small = T == 1 && mtb <= small_mt && !no_small_;
     // Fewer than 256 m-tiles: the chunked recurrent kernels would occupy mtb workgroups, so the layers run frame
@@ -575,7 +589,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     // in fp32 at 256 streams x 32 frames 8 x 32 launches of ~13 us beat 8 x (0.1 + 0.75) ms (2.8 vs 1.2 M frames/s; 5.5 vs
     // 3.7 M at 1024 streams, 7.2 vs 6.7 M at 3072, equal at 4096).  Frame t of a call reads the hidden
     // state from ping-pong buffer (hs_cur_ + t) & 1 and writes the other one.
-    static const int steps_mt = getenv("KOALA_AMD_STEPS_MT") ? atoi(getenv("KOALA_AMD_STEPS_MT")) : 192;  // tuning switch
+    const int steps_mt = dev_steps_mt_;
     // (fp32 only: the bf16 recurrent kernel keeps its weights on chip and is faster than 8 us per frame and layer even
     // with 16 workgroups -- 11.3 vs 5.2 M frames/s at 256 streams; the fp32 one streams them: 1.2 vs 2.8 M)
     const bool small_steps = T > 1 && mtb <= steps_mt && prec_ != kBf16 && !no_small_;
@@ -633,7 +647,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     sy.twiddle = d_twiddle_;
     sy.tail_in = d_tail_[tail_cur_];
     sy.tail_out = d_tail_[in_place ? tail_cur_ : tail_cur_ ^ 1];
-    static const int seg_env = getenv("KOALA_AMD_SYNTH_SEG") ? atoi(getenv("KOALA_AMD_SYNTH_SEG")) : 0;
+    const int seg_env = dev_synth_seg_;
     // two segments per stream tile (512 workgroups at B = 4096) measured best: fewer, longer segments amortise the
     // one replayed frame; a single segment leaves half the chip without a second workgroup to overlap with
     // ... and with few stream tiles the segments shrink (down to 4 frames) until there are about two workgroups per CU
@@ -784,8 +798,15 @@ bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err, 
         const bool overlap = pcm < out + n && out < pcm + n;
         return run_device(T, pcm, out, err, !overlap);
     }
-    if (T > host_chunk_ && bytes >= host_pipeline_min_bytes_)
+    if (T > host_chunk_ && bytes >= host_pipeline_min_bytes_) {
+        const char *pa = (const char *) pcm, *pb = (const char *) out;
+        if (pa < pb + bytes && pb < pa + bytes) {  // chunk c's copy-out would land on input chunks not yet read
+            *err = "`pcm` and `enhanced` overlap: host-memory calls of this size are pipelined in sub-chunks and need "
+                   "disjoint buffers.";
+            return false;
+        }
         return process_host_pipelined(T, pcm, out, kin == kPtrPinned && kout == kPtrPinned, err);
+    }
     memcpy(h_in_, pcm, bytes);
     if (T == 1 && use_graph_ && stream_ == own_stream_ && !profiling_) {
         // frame-by-frame streaming: (copy-in,) the kernels of one frame (and copy-out) replayed as one hipGraph
@@ -885,6 +906,11 @@ int64_t Engine::debug_read(int what, float *out, int64_t capacity, std::string *
                 for (int k = 0; k < width; ++k)
                     out[((size_t) t * B_ + b) * width + k] = a_at(h, (size_t) t * mtb + b / 16, nb, b % 16, k);
     } else if (what == 1) {  // spectrum
+        if (!spec_valid_) {  // multi-frame calls rebuild the spectrum from the PCM and store none
+            *err = "the last call stored no spectrum (multi-frame calls recompute it): use the developer build with its "
+                   "debug-taps switch";
+            return -1;
+        }
         n = (int64_t) T * B_ * kBins * 2;
         if (n > capacity) return -2;
         auto h = fetch(d_spec_, (size_t) T * Bpad_ * 256 * 8);

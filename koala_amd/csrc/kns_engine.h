@@ -100,6 +100,9 @@ private:
     // hipGraph of one host-pointer frame (copy-in, 23 kernels, copy-out); built on first use
     hipGraphExec_t frame_graph_[8] = {};  // one per combination of the hidden-state / history / tail ping-pong indices
     bool use_graph_ = true, no_small_ = false, no_zero_copy_ = false, no_recompute_ = false, debug_taps_ = false;
+    // developer switches (all read once in init() through dev_env(): compiled out of the product library)
+    int dev_variant_ = 0, dev_only_class_ = -1, dev_analysis_seg_ = 0, dev_synth_seg_ = 0, dev_small_mt_ = 0, dev_steps_mt_ = 192;
+    bool spec_valid_ = false;  // the last run_device() stored the spectrum (debug_read(1) refuses otherwise)
 
     // profiling
     bool profiling_ = false;

@@ -514,7 +514,7 @@ static void launch_gemm_p(const GemmArgs &a, hipStream_t s) {
 }
 
 void launch_gemm(const GemmArgs &a, hipStream_t s) {
-    static const bool no_ws = getenv("KOALA_AMD_GEMM_GENERIC") != nullptr;  // A/B switch for profiling
+    const bool no_ws = (a.dev & kDevGemmGeneric) != 0;  // A/B switch (developer build only)
     if (a.precision == kBf16 && a.out_kind == kOutGi && a.ntiles == kGateTiles && a.nb1 == PBF16::NBH && a.nb0 <= 2 &&
         a.mtiles >= 256 && !no_ws) {
         // The weight-stationary kernel splits the m-tiles over 256 workgroup pairs: it takes the largest multiple of 256,
@@ -548,7 +548,7 @@ void launch_gemm(const GemmArgs &a, hipStream_t s) {
         }
         return;
     }
-    static const bool no_wsr = getenv("KOALA_AMD_GEMM_NO_WSR") != nullptr;  // A/B switch
+    const bool no_wsr = (a.dev & kDevGemmNoWsr) != 0;  // A/B switch (developer build only)
     if (a.precision == kBf16 && a.nb0 == 0 && a.nb1 == PBF16::NBH && a.mtiles >= 512 && !no_wsr) {
         const dim3 grid(256), block(512);
         if (a.out_kind == kOutAPlain && a.ntiles <= 32) {

@@ -509,7 +509,7 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
 }
 
 void launch_gru(const GruArgs &a, hipStream_t s) {
-    static const bool stream_weights = getenv("KOALA_AMD_GRU_STREAM") != nullptr;  // A/B switch for profiling
+    const bool stream_weights = (a.dev & kDevGruStream) != 0;  // A/B switch (developer build only)
     if (a.precision == kBf16 && !stream_weights)
         hipLaunchKernelGGL(gru_resident8_kernel, dim3(a.mtiles), dim3(64 * kR8Waves), 0, s, a);
     else if (a.precision == kBf16)

@@ -3,10 +3,21 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "kns_layout.h"
 
 namespace kns {
+
+// Developer switches (kernel A/B selection, tuning knobs, probing modes) exist only in the -DKNS_DEV build
+// (lib/libpv_koala_dev.so, used by tests/ and tools/); the product library reads none of them.
+#ifdef KNS_DEV
+inline const char *dev_env(const char *name) { return getenv(name); }
+#else
+inline const char *dev_env(const char *) { return nullptr; }
+#endif
+// kernel-family overrides carried in the launch arguments (set by the engine from its developer switches; 0 in the product)
+enum DevVariant { kDevGruStream = 1, kDevGemmGeneric = 2, kDevGemmNoWsr = 4 };
 
 // ---- analysis: int16 frames -> spectrum + normalised log-power features (SURVEY 8a rows a2+a3)
 struct AnalysisArgs {
@@ -60,6 +71,7 @@ struct GemmArgs {
     int mtiles, ntiles;
     int n_valid;  // logical output width; columns >= n_valid are written as 0 in A-packed outputs
     int out_kind, precision;
+    int dev = 0;  // DevVariant bits
 };
 void launch_gemm(const GemmArgs &a, hipStream_t s);
 
@@ -73,6 +85,7 @@ struct GruArgs {
                              // state tiles in every workgroup, so it may not be updated in place)
     void *hseq;         // A-packed [T][mtiles][nbh] blocks, out
     int T, mtiles, precision;
+    int dev = 0;  // DevVariant bits
 };
 void launch_gru(const GruArgs &a, hipStream_t s);
 

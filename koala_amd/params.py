@@ -98,12 +98,19 @@ def make_random(seed: int = 1234, gain: float = 1.0) -> Dict[str, np.ndarray]:
     return t
 
 
-def noise_prior() -> np.ndarray:
-    """Mean log-power per bin of the reference's noise fixture (tools/make_noise_prior.py)."""
-    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "noise_prior.npy"))
+def noise_prior(noise_pcm: np.ndarray) -> np.ndarray:
+    """Mean log-power per bin of a stationary-noise recording under KNS-v1's own analysis (sqrt-Hann 512/256, samples /
+    32768): what `make_gate` turns into its per-bin threshold.  The package ships no such table -- the `gate` kind is a
+    test-only model that tests/conftest.py builds from the reference's noise fixture (tests/golden/noise.wav)."""
+    x = np.asarray(noise_pcm, np.int16).astype(np.float64) / 32768.0
+    n = len(x) // 256 * 256
+    win = np.sin(np.pi * np.arange(512) / 512)
+    frames = np.stack([x[i:i + 512] * win for i in range(0, n - 512 + 1, 256)])
+    logp = np.log(np.abs(np.fft.rfft(frames, axis=1)) ** 2 + 1e-10)
+    return logp.mean(0).astype(np.float32)
 
 
-def make_gate(threshold: Optional[np.ndarray] = None, margin: float = 2.15, g1: float = 0.8, z_a: float = 0.2,
+def make_gate(threshold: Optional[np.ndarray] = None, g1: float = 0.8, z_a: float = 0.2,
               g2: float = 1.2, z_b: float = 1e-4, g3: float = 10.0, smooth: int = 1, gv: float = 0.8, zv: float = 0.8,
               kappa: float = 4.0, theta: float = -0.45, zvb: float = 0.6, a: float = 4.0, beta: float = 0.4,
               width: float = 20.0) -> Dict[str, np.ndarray]:
@@ -123,7 +130,7 @@ def make_gate(threshold: Optional[np.ndarray] = None, margin: float = 2.15, g1: 
     """
     t = {name: np.zeros(shape, np.float32) for name, shape in tensor_order()}
     if threshold is None:
-        threshold = noise_prior() + margin
+        raise ValueError("make_gate needs `threshold` (e.g. noise_prior(pcm) + 2.15): the package ships no noise prior")
     t["mean"][:] = threshold
     t["scale"][:] = 1.0
     w_in = np.zeros((BINS, HIDDEN), np.float32)

@@ -451,7 +451,7 @@ typedef struct {
 
 /* one frame for a block of nb streams */
 static void frame_block(const kns_params_t *p, int nb, kns_stream_t **st, const int16_t **pcm, int16_t **out,
-                        kns_scratch_t *w, kns_taps_t *taps) {
+                        kns_scratch_t *w, kns_taps_t *taps, float **mask_out) {
     const int bf = p->precision == KNS_PREC_BF16;
     for (int s = 0; s < nb; ++s) {
         analysis(p, st[s]->hist, pcm[s], w->spec[s], w->feat[s]);
@@ -512,6 +512,8 @@ static void frame_block(const kns_params_t *p, int nb, kns_stream_t **st, const 
         tap_off += g->d_out;
     }
     for (int s = 0; s < nb; ++s) synthesis(p, w->spec[s], w->y[s], st[s]->tail, out[s]);
+    if (mask_out)
+        for (int s = 0; s < nb; ++s) memcpy(mask_out[s], w->y[s], sizeof(float) * KNS_BINS);
     if (taps) {
         if (taps->spectrum) memcpy(taps->spectrum, w->spec[0], sizeof(float) * KNS_BINS * 2);
         if (taps->features) memcpy(taps->features, w->feat[0], sizeof(float) * KNS_BINS);
@@ -547,6 +549,11 @@ static int g_last_block = KNS_MAX_BLOCK;
 int kns_oracle_last_block(void) { return g_last_block; }
 
 int kns_oracle_process(kns_oracle_t *o, int num_frames, const int16_t *pcm, int16_t *enhanced, int num_threads) {
+    return kns_oracle_process_mask(o, num_frames, pcm, enhanced, NULL, num_threads);
+}
+
+int kns_oracle_process_mask(kns_oracle_t *o, int num_frames, const int16_t *pcm, int16_t *enhanced, float *mask,
+                            int num_threads) {
     if (!o || !pcm || !enhanced || num_frames <= 0) return -1;
     const int B = o->num_streams;
     const size_t row = (size_t) num_frames * KNS_FRAME;
@@ -572,13 +579,15 @@ int kns_oracle_process(kns_oracle_t *o, int num_frames, const int16_t *pcm, int1
         kns_stream_t *st[KNS_MAX_BLOCK];
         const int16_t *in[KNS_MAX_BLOCK];
         int16_t *out[KNS_MAX_BLOCK];
+        float *mk[KNS_MAX_BLOCK];
         for (int t = 0; t < num_frames; ++t) {
             for (int s = 0; s < nb; ++s) {
                 st[s] = &o->st[s0 + s];
                 in[s] = pcm + (size_t) (s0 + s) * row + (size_t) t * KNS_FRAME;
                 out[s] = enhanced + (size_t) (s0 + s) * row + (size_t) t * KNS_FRAME;
+                if (mask) mk[s] = mask + ((size_t) t * B + (size_t) (s0 + s)) * KNS_BINS;
             }
-            frame_block(o->p, nb, st, in, out, w, NULL);
+            frame_block(o->p, nb, st, in, out, w, NULL, mask ? mk : NULL);
         }
         free(w);
     }
@@ -590,7 +599,7 @@ int kns_oracle_process_tap(kns_oracle_t *o, int s, const int16_t *pcm, int16_t *
     kns_scratch_t *w = (kns_scratch_t *) malloc(sizeof(kns_scratch_t));
     memset(w->y, 0, sizeof(w->y));
     kns_stream_t *st = &o->st[s];
-    frame_block(o->p, 1, &st, &pcm, &enhanced, w, taps);
+    frame_block(o->p, 1, &st, &pcm, &enhanced, w, taps, NULL);
     free(w);
     return 0;
 }

@@ -70,6 +70,10 @@ int kns_oracle_delay_sample(void);
 /* pcm, enhanced: [num_streams][num_frames*256] row-major int16.  num_threads<=0 -> all cores. */
 int kns_oracle_process(kns_oracle_t *o, int num_frames, const int16_t *pcm, int16_t *enhanced, int num_threads);
 
+/* the same, also returning every frame's mask y_4 as [num_frames][num_streams][257] (NULL: no masks) */
+int kns_oracle_process_mask(kns_oracle_t *o, int num_frames, const int16_t *pcm, int16_t *enhanced, float *mask,
+                            int num_threads);
+
 /* streams per block used by the last kns_oracle_process call (reporting only) */
 int kns_oracle_last_block(void);
 

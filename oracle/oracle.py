@@ -43,6 +43,7 @@ def lib():
         l.kns_oracle_delete.argtypes = [C.c_void_p]
         l.kns_oracle_reset.argtypes = [C.c_void_p, C.c_void_p]
         l.kns_oracle_process.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        l.kns_oracle_process_mask.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         l.kns_oracle_process_tap.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(_Taps)]
         l.kns_oracle_analysis.argtypes = [C.c_void_p] * 5
         l.kns_oracle_synthesis.argtypes = [C.c_void_p] * 4
@@ -89,6 +90,16 @@ class Oracle:
         if rc != 0:
             raise RuntimeError("kns_oracle_process failed")
         return out.reshape(a.shape)
+
+    def process_with_mask(self, pcm: np.ndarray, num_threads: int = 0):
+        """pcm int16 [num_streams, T*256] -> (enhanced, mask float32 [T, num_streams, 257])"""
+        a = np.ascontiguousarray(pcm, dtype=np.int16).reshape(self.num_streams, -1)
+        T = a.shape[1] // FRAME
+        out = np.empty_like(a)
+        mask = np.empty((T, self.num_streams, BINS), np.float32)
+        if self._l.kns_oracle_process_mask(self._o, T, _ptr(a), _ptr(out), _ptr(mask), num_threads) != 0:
+            raise RuntimeError("kns_oracle_process_mask failed")
+        return out, mask
 
     def process_tap(self, frame: np.ndarray, stream: int = 0):
         """one frame of one stream; returns (enhanced[256], dict of intermediates)"""

@@ -74,6 +74,34 @@ def test_exports_every_declared_symbol(native_library):
         assert hasattr(l, name), name
 
 
+def test_dynamic_symbol_table_is_the_abi_and_nothing_else(native_library):
+    """The linker version script (koala_amd/csrc/libpv_koala.map) keeps kernel stubs, __hip_cuid_* and libstdc++ template
+    instances out of the dynamic symbol table: what a dlsym caller can see is the reference ABI + the batch extension."""
+    import subprocess
+    for lib in (native_library, koala_amd.developer_library_path()):
+        out = subprocess.run(['nm', '-D', '--defined-only', lib], capture_output=True, text=True, check=True).stdout
+        names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+        assert len(names) >= 30
+        stray = [n for n in names if not n.startswith('pv_')]
+        assert not stray, stray
+    # ... and it is a superset of what the reference's own library exports (captured list, SURVEY.md 8b)
+    ref = set('pv_free pv_free_error_stack pv_get_error_stack pv_get_sdk pv_koala_delay_sample pv_koala_delete '
+              'pv_koala_frame_length pv_koala_free_hardware_devices pv_koala_init pv_koala_list_hardware_devices pv_koala_process '
+              'pv_koala_reset pv_koala_version pv_log_disable pv_log_enable pv_sample_rate pv_set_sdk pv_status_to_string'.split())
+    assert ref <= set(names)
+
+
+def test_product_library_reads_no_developer_switch(native_library):
+    """KOALA_AMD_ONLY_CLASS & co. exist in the -DKNS_DEV build only: their names do not even occur in the product binary."""
+    blob = open(native_library, 'rb').read()
+    dev = open(koala_amd.developer_library_path(), 'rb').read()
+    for name in (b'KOALA_AMD_ONLY_CLASS', b'KOALA_AMD_GRU_STREAM', b'KOALA_AMD_GEMM_GENERIC', b'KOALA_AMD_SMALL_MT',
+                 b'KOALA_AMD_DEBUG_TAPS', b'KOALA_AMD_HOST_CHUNK'):
+        assert name not in blob, name
+        assert name in dev, name
+    assert b'KOALA_AMD_PRECISION' in blob  # the one documented run-time option of the single-stream ABI
+
+
 def test_constants(lib, fx):
     assert lib.pv_koala_version().decode() == fx['version']
     assert lib.pv_koala_frame_length() == fx['frame_length']

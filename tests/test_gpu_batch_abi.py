@@ -110,3 +110,33 @@ def test_host_alloc_edges(lib):
     C.memset(p, 0x5a, 1 << 20)
     lib.pv_koala_batch_host_free(p)
     lib.pv_koala_batch_host_free(None)
+
+
+def test_overlapping_host_buffers_are_refused_where_the_call_is_pipelined(lib, random_model):
+    """include/pv_koala_batch.h: host-pointer calls of >= 4 MiB run as overlapping sub-chunks and need disjoint buffers; smaller
+    ones are staged as a whole and may be processed in place."""
+    B, T = 300, 32  # 300 x 32 x 512 B = 4.9 MB: pipelined
+    st, h = open_batch(lib, random_model, B, T)
+    assert st == SUCCESS
+    x = synth_streams(B, T, seed=11)
+    buf = np.concatenate([x, x], axis=1).copy()  # room for a shifted output inside one allocation
+    flat = buf.reshape(-1)
+    n = B * T * 256
+    assert lib.pv_koala_batch_process_chunk(h, T, flat[:n].ctypes.data, flat[256:].ctypes.data) == RUNTIME_ERROR
+    assert any('overlap' in m for m in stack(lib))
+    a = np.ascontiguousarray(x)
+    y = np.empty_like(a)
+    assert lib.pv_koala_batch_process_chunk(h, T, a.ctypes.data, y.ctypes.data) == SUCCESS  # state untouched by the refusal
+    ref = koala_amd.create_batch('key', B, T, 'bf16', model_path=random_model)
+    assert np.array_equal(ref.process(a), y)
+    ref.delete()
+    lib.pv_koala_batch_delete(h)
+    # small call: staged as a whole, exact aliasing allowed
+    st, h = open_batch(lib, random_model, 20, 4)
+    s = np.ascontiguousarray(synth_streams(20, 4, seed=12))
+    want = koala_amd.create_batch('key', 20, 4, 'bf16', model_path=random_model)
+    expect = want.process(s)
+    want.delete()
+    assert lib.pv_koala_batch_process_chunk(h, 4, s.ctypes.data, s.ctypes.data) == SUCCESS
+    assert np.array_equal(s, expect)
+    lib.pv_koala_batch_delete(h)

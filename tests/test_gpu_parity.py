@@ -20,7 +20,11 @@ import os as _os
 # bf16 engine vs the oracle with the same rounding points: the two differ only in the gate / head / log transcendentals
 # (hardware v_exp / v_rcp / v_log against the spec's polynomials).  Largest difference ever measured in this suite: see
 # DESIGN.md section 5.
-BF16_TOL = int(_os.environ.get('KOALA_TEST_BF16_TOL', '4'))  # measured maximum 3 LSB
+# Bar 5 LSB (the same as __graft_entry__.smoke(), whose white-noise sample measures 4; this suite's own maximum is 3) plus the
+# distribution checked wherever a histogram is taken: >= 99 % of the samples within 1 LSB.
+BF16_TOL = int(_os.environ.get('KOALA_TEST_BF16_TOL', '5'))
+# the -DKNS_DEV build of the same sources: the only library that reads the KOALA_AMD_* developer switches
+DEV_LIB = koala_amd.developer_library_path()
 
 
 def run_oracle(model, x, precision=oracle.PREC_FP32):
@@ -36,7 +40,7 @@ def test_fp32_stage_taps_and_pcm(random_model, monkeypatch, B, T, calls):
     # (multi-frame calls do not store the spectrum at all -- the synthesis kernel rebuilds it -- unless the taps are on)
     monkeypatch.setenv('KOALA_AMD_DEBUG_TAPS', '1')
     x = synth_streams(B, T * calls, seed=100 + B)
-    kb = koala_amd.create_batch('key', B, T, 'fp32', model_path=random_model)
+    kb = koala_amd.create_batch('key', B, T, 'fp32', model_path=random_model, library_path=DEV_LIB)
     streams = [oracle.Oracle(random_model) for _ in range(B)]
     for c in range(calls):
         xc = np.ascontiguousarray(x[:, c * T * 256:(c + 1) * T * 256])
@@ -94,6 +98,30 @@ def test_bf16_against_both_oracles(random_model, test_pcm):
     print('bf16 engine vs bf16-rounding oracle, |diff| histogram 0..8+:', hist.tolist(), 'mask rms vs fp32:', rms)
     assert d.max() <= BF16_TOL and (d == 0).mean() > 0.75 and (d <= 1).mean() > 0.99
     assert lsb(out, run_oracle(random_model, x)).max() <= 24  # against the unrounded oracle
+
+
+@pytest.mark.parametrize('B,T,calls', [(256, 16, 2), (1024, 8, 1)])
+def test_bf16_mask_rms_at_batch_scale(random_model, B, T, calls):
+    """north_star's criterion for the bf16 configuration -- mask within 1e-3 RMS of the floating-point (fp32) path -- over
+    every stream, frame and bin of a batch of distinct streams (bench.py reports the same over its 1 024 distinct streams x 64
+    frames at 4096 streams: `parity.mask_rms_vs_fp32_oracle`)."""
+    x = synth_streams(B, T * calls, seed=77)
+    kb = koala_amd.create_batch('key', B, T, 'bf16', model_path=random_model)
+    ref = oracle.Oracle(random_model, B, oracle.PREC_FP32)
+    sq, n, worst = 0.0, 0, 0.0
+    for c in range(calls):
+        xc = np.ascontiguousarray(x[:, c * T * 256:(c + 1) * T * 256])
+        kb.process(xc)
+        got = kb.debug_read('mask', T)
+        _, want = ref.process_with_mask(xc)
+        d = got.astype(np.float64) - want
+        sq += float(np.sum(d * d))
+        n += d.size
+        worst = max(worst, float(np.abs(d).max()))
+    kb.delete()
+    rms = np.sqrt(sq / n)
+    print('bf16 mask vs fp32 oracle over %d values: rms %.3e, max %.3e' % (n, rms, worst))
+    assert rms < 1e-3, rms
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
@@ -176,7 +204,7 @@ def test_host_pointer_calls_are_pipelined_without_changing_results(random_model,
     torch = pytest.importorskip('torch')
     monkeypatch.setenv('KOALA_AMD_HOST_CHUNK', chunk)  # small calls are not split unless told to
     x = synth_streams(B, 2 * T, seed=5)
-    kb = koala_amd.create_batch('key', B, Tmax, 'bf16', model_path=random_model)
+    kb = koala_amd.create_batch('key', B, Tmax, 'bf16', model_path=random_model, library_path=DEV_LIB)
     dx = torch.from_numpy(x).cuda()
     dy = torch.zeros_like(dx[:, :T * 256].contiguous())
     ref = []
@@ -285,7 +313,7 @@ from koala_amd.workload import synth_streams
 h = hashlib.sha256()
 for precision, B, T in (('bf16', 4096, 4), ('bf16', 272, 3), ('fp32', 512, 2)):
     x = np.tile(synth_streams(16, 2 * T, seed=9), ((B + 15) // 16, 1))[:B]
-    kb = koala_amd.create_batch('key', B, T, precision, model_path=%(model)r)
+    kb = koala_amd.create_batch('key', B, T, precision, model_path=%(model)r, library_path=%(lib)r)
     for c in range(2):
         h.update(kb.process(np.ascontiguousarray(x[:, c * T * 256:(c + 1) * T * 256])).tobytes())
     kb.delete()
@@ -300,8 +328,15 @@ def test_alternative_kernels_give_identical_pcm(random_model):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = _SWITCH_SCRIPT % {'root': root, 'tests': os.path.join(root, 'tests'), 'model': random_model}
     digests = {}
+    # the product library (which reads no switch) is one arm, the developer build under each of its switches the others
+    script = _SWITCH_SCRIPT % {'root': root, 'tests': os.path.join(root, 'tests'), 'model': random_model,
+                               'lib': koala_amd.default_library_path()}
+    out = subprocess.run([sys.executable, '-c', script], env=dict(os.environ, KOALA_AMD_GEMM_GENERIC='1'),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    digests['product'] = [ln for ln in out.stdout.splitlines() if ln.startswith('DIGEST')][-1]
+    script = _SWITCH_SCRIPT % {'root': root, 'tests': os.path.join(root, 'tests'), 'model': random_model, 'lib': DEV_LIB}
     for switch in ('', 'KOALA_AMD_GRU_STREAM', 'KOALA_AMD_GEMM_GENERIC',
                    'KOALA_AMD_GEMM_NO_WSR', 'KOALA_AMD_NO_SMALL', 'KOALA_AMD_NO_GRAPH', 'KOALA_AMD_STORE_SPECTRUM',
                    'KOALA_AMD_DEBUG_TAPS'):

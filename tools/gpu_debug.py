@@ -20,13 +20,14 @@ def synth(B, T, seed=0):
 
 
 def main():
+    os.environ['KOALA_AMD_DEBUG_TAPS'] = '1'  # multi-frame calls store no spectrum otherwise (developer library only)
     koala_amd.build_native()
     model = params.ensure_params(os.path.join(ROOT, 'build', 'random_1234.kns'), 'random', 1234)
     print('devices', koala_amd.available_devices())
     for prec, oprec in (('fp32', oracle.PREC_FP32), ('bf16', oracle.PREC_BF16)):
         for (B, T, calls) in ((19, 3, 2), (1, 1, 3), (40, 8, 1)):
             x = synth(B, T * calls, seed=B)
-            kb = koala_amd.create_batch('key', B, T, prec, model_path=model)
+            kb = koala_amd.create_batch('key', B, T, prec, model_path=model, library_path=koala_amd.developer_library_path())
             orc = [oracle.Oracle(model, 1, oprec) for _ in range(B)]
             worst = {}
             for c in range(calls):
@@ -49,7 +50,7 @@ def main():
     # throughput smoke
     for prec in ('fp32', 'bf16'):
         B, T = 4096, 8
-        kb = koala_amd.create_batch('key', B, T, prec, model_path=model)
+        kb = koala_amd.create_batch('key', B, T, prec, model_path=model, library_path=koala_amd.developer_library_path())
         x = synth(B, T, 7)
         kb.process(x)
         t0 = time.time()

@@ -22,7 +22,7 @@ for chunk in (None, '0'):
         os.environ.pop('KOALA_AMD_HOST_CHUNK', None)
     else:
         os.environ['KOALA_AMD_HOST_CHUNK'] = chunk
-    kb = koala_amd.create_batch('k', B, T, 'bf16', model_path=model)
+    kb = koala_amd.create_batch('k', B, T, 'bf16', model_path=model, library_path=koala_amd.developer_library_path())
     pin_in, pin_out = kb.alloc_host(T), kb.alloc_host(T)
     pin_in[:] = x
     out = np.empty_like(x)

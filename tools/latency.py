@@ -23,7 +23,7 @@ def wav(name):
 
 def main():
     koala_amd.build_native()
-    model = params.ensure_params(os.path.join(ROOT, 'build', 'gate.kns'), 'gate')
+    model = koala_amd.default_model_path()  # the packaged adaptive-floor gate
     pcm = wav('test.wav')
     n = len(pcm) // 256
     frames = [np.ascontiguousarray(pcm[i * 256:(i + 1) * 256]) for i in range(n)]

@@ -9,7 +9,7 @@ for B in (4096, 2048, 512):
     x = torch.from_numpy(np.tile(synth_streams(64, 1, 1), (B // 64, 1))).cuda()
     y = torch.empty_like(x)
     for prec in ('fp32',):
-        kb = koala_amd.create_batch('k', B, 1, prec, model_path=model)
+        kb = koala_amd.create_batch('k', B, 1, prec, model_path=model, library_path=koala_amd.developer_library_path())
         kb.set_stream(torch.cuda.current_stream().cuda_stream)
         for _ in range(50): kb.process_device(1, x.data_ptr(), y.data_ptr())
         torch.cuda.synchronize(); t0=time.perf_counter()
