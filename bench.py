@@ -58,6 +58,9 @@ def parse_args():
     ap.add_argument('--prime-seconds', type=float, default=0.5,
                     help='untimed run of the same step before the warmup steps: the MI355X takes a few hundred ms of load to '
                          'leave its idle clocks (sclk ~100 MHz), and the workload then runs against the 1400 W board power cap')
+    ap.add_argument('--sustain-seconds', type=float, default=3.0,
+                    help='untimed stretch of the same step after the timed region during which the sustained sclk / board power '
+                         'are sampled (0: skip)')
     ap.add_argument('--streams', type=int, default=4096, help='streams per GPU')
     ap.add_argument('--frames', type=int, default=64, help='frames per stream per call (64 = 1.02 s of audio)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
@@ -116,10 +119,11 @@ class BoardSampler(object):
         cards = sorted(glob.glob('/sys/class/drm/card[0-9]*/device/pp_dpm_sclk'))
         if index < len(cards):
             self._sclk = cards[index]
-            hw = sorted(glob.glob(os.path.join(os.path.dirname(cards[index]), 'hwmon', 'hwmon*', 'power1_average')) +
-                        glob.glob(os.path.join(os.path.dirname(cards[index]), 'hwmon', 'hwmon*', 'power1_input')))
+            hw = (sorted(glob.glob(os.path.join(os.path.dirname(cards[index]), 'hwmon', 'hwmon*', 'power1_input'))) +
+                  sorted(glob.glob(os.path.join(os.path.dirname(cards[index]), 'hwmon', 'hwmon*', 'power1_average'))))
             self._power = hw[0] if hw else None
         self._thread = threading.Thread(target=self._run, daemon=True)
+        self.t0 = time.perf_counter()
 
     def _read(self):
         mhz, watts = None, None
@@ -137,7 +141,7 @@ class BoardSampler(object):
 
     def _run(self):
         while not self._stop.is_set():
-            self.samples.append(self._read())
+            self.samples.append(self._read() + (time.perf_counter() - self.t0,))
             self._stop.wait(0.05)
 
     def __enter__(self):
@@ -150,13 +154,15 @@ class BoardSampler(object):
         if self._sclk:
             self._thread.join()
 
-    def summary(self):
+    def summary(self, after_seconds=0.0):
+        """over the samples taken later than `after_seconds` (the SMU's reported clock settles over a second or two of load)"""
         import statistics
-        mhz = [m for m, _ in self.samples if m]
-        w = [p for _, p in self.samples if p]
+        mhz = [m for m, _, t in self.samples if m and t >= after_seconds]
+        w = [p for _, p, t in self.samples if p and t >= after_seconds]
         return {'sclk_MHz_median': statistics.median(mhz) if mhz else None, 'sclk_MHz_min': min(mhz) if mhz else None,
-                'board_power_W_mean': round(sum(w) / len(w), 1) if w else None, 'samples': len(self.samples),
-                'peak_sclk_MHz': self.PEAK_SCLK_MHZ, 'source': 'amdgpu sysfs pp_dpm_sclk / hwmon power1_average'}
+                'board_power_W_mean': round(sum(w) / len(w), 1) if w else None, 'samples': len(mhz),
+                'peak_sclk_MHz': self.PEAK_SCLK_MHZ,
+                'source': 'amdgpu sysfs pp_dpm_sclk / %s' % (os.path.basename(self._power) if self._power else None)}
 
 
 def time_steps(fn, sync, steps, warmup):
@@ -364,6 +370,22 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
     board = board.summary()
+    # The timed region is short (K steps of ~3 ms) and starts right after the clock ramp: the board is still above the clock it
+    # can SUSTAIN under its 1.4 kW cap.  A further untimed stretch of the same step gives the sustained figures the MFMA
+    # fractions are also quoted against (`frac_at_sustained_sclk`), and the throughput at that point.
+    sustained = None
+    if rank == 0 and args.sustain_seconds > 0:
+        with BoardSampler(local_rank) as sb:
+            n_s, t_s = 0, time.perf_counter()
+            while time.perf_counter() - t_s < args.sustain_seconds:
+                for _ in range(50):
+                    step()
+                torch.cuda.synchronize()
+                n_s += 50
+            dt_s = time.perf_counter() - t_s
+        sustained = sb.summary(after_seconds=args.sustain_seconds / 2.0)
+        sustained['seconds'] = round(dt_s, 2)
+        sustained['frames_per_s'] = round(B * T * n_s / dt_s, 1)
     frames_total, elapsed_max = aggregate_throughput(B * T * args.steps, elapsed)
     value = frames_total / elapsed_max
 
@@ -401,9 +423,10 @@ def main():
                         'frac': round(achieved / peak, 5), 'avg_launch_ms': round(ms, 5),
                         'launches_per_step': round(actual, 2) if actual != int(actual) else int(actual),
                         'share_of_device_time': round(ms * actual / dev_ms, 4) if dev_ms else None}
-        if bound == 'mfma' and board.get('sclk_MHz_median'):
-            # the same fraction against the matrix peak AT THE CLOCK THE BOARD SUSTAINED under its power cap in the timed region
-            stages[name]['frac_at_sustained_sclk'] = round(achieved / (peak * board['sclk_MHz_median'] / board['peak_sclk_MHz']), 5)
+        clk = (sustained or board).get('sclk_MHz_median')
+        if bound == 'mfma' and clk:
+            # the same fraction against the matrix peak AT THE CLOCK THE BOARD SUSTAINS under its power cap with this workload
+            stages[name]['frac_at_sustained_sclk'] = round(achieved / (peak * clk / BoardSampler.PEAK_SCLK_MHZ), 5)
         if name in ('analysis', 'synthesis'):
             # limited by VALU issue, not by HBM: `frac` prices the bytes the dataflow needs, and
             # `frac_of_peak_by_traffic` (below) the bytes the kernel was measured to move
@@ -491,7 +514,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra:
         extra = extra_points(args, torch, np, koala_amd, model, kb, x, dx, dy, base, local_rank)
     # the constants the fractions are divided by, next to what a plain device-to-device copy reaches on this box
-    peaks = {'hbm_GBps': HBM_PEAK_GBS, 'mfma_TFLOPs': MFMA_PEAK_TFLOPS[args.precision], 'board_during_timed_region': board}
+    peaks = {'hbm_GBps': HBM_PEAK_GBS, 'mfma_TFLOPs': MFMA_PEAK_TFLOPS[args.precision], 'board_during_timed_region': board, 'board_sustained': sustained}
     if rank == 0:
         src = torch.empty(1 << 30, dtype=torch.uint8, device='cuda')
         dst = torch.empty_like(src)

@@ -100,7 +100,7 @@ def test_bf16_against_both_oracles(random_model, test_pcm):
     assert lsb(out, run_oracle(random_model, x)).max() <= 24  # against the unrounded oracle
 
 
-@pytest.mark.parametrize('B,T,calls', [(256, 16, 2), (1024, 8, 1)])
+@pytest.mark.parametrize('B,T,calls', [(256, 16, 2), (1024, 4, 2)])  # (host calls below 4 MiB: not cut into sub-chunks)
 def test_bf16_mask_rms_at_batch_scale(random_model, B, T, calls):
     """north_star's criterion for the bf16 configuration -- mask within 1e-3 RMS of the floating-point (fp32) path -- over
     every stream, frame and bin of a batch of distinct streams (bench.py reports the same over its 1 024 distinct streams x 64

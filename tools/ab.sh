@@ -5,7 +5,7 @@
 cd "$(dirname "$0")/.."
 for rep in $(seq 1 ${AB_REPS:-2}); do
   for lib in "$@"; do
-    python bench.py --library $PWD/$lib --no-cpu-baseline --no-extra --steps ${AB_STEPS:-400} 2>/dev/null | python -c "
+    python bench.py --library $PWD/$lib --no-cpu-baseline --no-extra --sustain-seconds 0 --steps ${AB_STEPS:-400} 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('$lib rep $rep: %.2f Mframes/s  %.4f ms/step | ' % (d['value']/1e6, d['ms_per_step']) + '  '.join('%s %.1f' % (k, v['avg_launch_ms']*1e3) for k,v in d['stages'].items()))"

@@ -8,8 +8,8 @@ classes=${@:-all 0 1 2 3 4}
 names=(analysis gemm_input gru_recurrent gemm_head synthesis)
 echo "# $(date -u +%FT%TZ) commit $(cat build/head_commit.txt 2>/dev/null) ; power cap: $(rocm-smi --showmaxpower 2>/dev/null | grep -i 'max' | sed 's/.*: //' | tr '\n' ' ')"
 for c in $classes; do
-  if [ "$c" = all ]; then unset KOALA_AMD_ONLY_CLASS; label=all; steps=${PROBE_STEPS_ALL:-5000}; else export KOALA_AMD_ONLY_CLASS=$c; label=${names[$c]}; steps=${PROBE_STEPS_ONE:-20000}; fi
-  python bench.py --library $PWD/koala_amd/lib/libpv_koala_dev.so --steps $steps --warmup 3 --no-cpu-baseline --no-extra > /tmp/bench_probe.json 2>/dev/null &
+  if [ "$c" = all ]; then unset KOALA_AMD_ONLY_CLASS; label=all; steps=${PROBE_STEPS_ALL:-5000}; else export KOALA_AMD_ONLY_CLASS=$c; label=${names[$c]}; steps=${PROBE_STEPS_ONE:-20000}; case $c in 0|3|4) steps=$((steps*8));; esac; fi
+  python bench.py --library $PWD/koala_amd/lib/libpv_koala_dev.so --steps $steps --warmup 3 --no-cpu-baseline --no-extra --sustain-seconds 0 > /tmp/bench_probe.json 2>/dev/null &
   BP=$!
   sleep ${PROBE_SETTLE:-9}
   echo "== $label"

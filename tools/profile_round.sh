@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/round_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python $ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extra > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python $ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extra --sustain-seconds 0 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 python $ROOT/tools/rocpd_summary.py $(ls $OUT/stats/*.db | head -1) $OUT/kernel_stats.txt > /dev/null
 rm -rf $OUT/stats
 bash $ROOT/tools/pmc_run.sh $TAG > /dev/null 2>&1
