@@ -58,7 +58,7 @@ def parse_args():
     ap.add_argument('--prime-seconds', type=float, default=0.5,
                     help='untimed run of the same step before the warmup steps: the MI355X takes a few hundred ms of load to '
                          'leave its idle clocks (sclk ~100 MHz), and the workload then runs against the 1400 W board power cap')
-    ap.add_argument('--sustain-seconds', type=float, default=3.0,
+    ap.add_argument('--sustain-seconds', type=float, default=4.0,
                     help='untimed stretch of the same step after the timed region during which the sustained sclk / board power '
                          'are sampled (0: skip)')
     ap.add_argument('--streams', type=int, default=4096, help='streams per GPU')
@@ -106,63 +106,58 @@ def launch_ranks(args):
 
 
 class BoardSampler(object):
-    """sclk and board power of one GPU from amdgpu's sysfs files while the timed region runs (a host thread reading two
-    small files every 50 ms; nothing is launched on the GPU).  Every field is None where the files do not exist."""
+    """sclk and board power of one GPU while a stretch of the workload runs: `rocm-smi --showclocks --showpower` called from a
+    host thread (each call takes a few hundred ms; nothing is launched on the GPU).  amdgpu's sysfs files (pp_dpm_sclk,
+    hwmon power1_*) were tried first and do not follow the load on this platform (2.39 GHz / 0.3 kW while rocm-smi and the
+    throughput say 1.98 GHz / 1.39 kW).  Every field is None where rocm-smi is missing."""
     PEAK_SCLK_MHZ = 2400.0  # MI355X peak engine clock: what the 2.5 PFLOP/s dense bf16 figure is quoted at
 
     def __init__(self, index):
-        import glob
         import threading
+        self.index = index
         self.samples = []
         self._stop = threading.Event()
-        self._sclk, self._power = None, None
-        cards = sorted(glob.glob('/sys/class/drm/card[0-9]*/device/pp_dpm_sclk'))
-        if index < len(cards):
-            self._sclk = cards[index]
-            hw = (sorted(glob.glob(os.path.join(os.path.dirname(cards[index]), 'hwmon', 'hwmon*', 'power1_input'))) +
-                  sorted(glob.glob(os.path.join(os.path.dirname(cards[index]), 'hwmon', 'hwmon*', 'power1_average'))))
-            self._power = hw[0] if hw else None
         self._thread = threading.Thread(target=self._run, daemon=True)
         self.t0 = time.perf_counter()
 
     def _read(self):
+        import re
         mhz, watts = None, None
         try:
-            for ln in open(self._sclk):
-                if '*' in ln:
-                    mhz = float(ln.split(':')[1].strip().split('M')[0])
-        except Exception:
-            pass
-        try:
-            watts = float(open(self._power).read()) / 1e6
+            out = subprocess.run(['rocm-smi', '-d', str(self.index), '--showclocks', '--showpower'], capture_output=True,
+                                 text=True, timeout=10).stdout
+            m = re.search(r'sclk clock level[^(]*\((\d+)Mhz\)', out)
+            if m:
+                mhz = float(m.group(1))
+            m = re.search(r'Power \(W\):\s*([0-9.]+)', out)
+            if m:
+                watts = float(m.group(1))
         except Exception:
             pass
         return mhz, watts
 
     def _run(self):
         while not self._stop.is_set():
-            self.samples.append(self._read() + (time.perf_counter() - self.t0,))
-            self._stop.wait(0.05)
+            t = time.perf_counter() - self.t0
+            self.samples.append(self._read() + (t,))
+            self._stop.wait(0.1)
 
     def __enter__(self):
-        if self._sclk:
-            self._thread.start()
+        self._thread.start()
         return self
 
     def __exit__(self, *a):
         self._stop.set()
-        if self._sclk:
-            self._thread.join()
+        self._thread.join()
 
     def summary(self, after_seconds=0.0):
-        """over the samples taken later than `after_seconds` (the SMU's reported clock settles over a second or two of load)"""
+        """over the samples STARTED later than `after_seconds` (the clock settles over a second or two of load)"""
         import statistics
         mhz = [m for m, _, t in self.samples if m and t >= after_seconds]
         w = [p for _, p, t in self.samples if p and t >= after_seconds]
         return {'sclk_MHz_median': statistics.median(mhz) if mhz else None, 'sclk_MHz_min': min(mhz) if mhz else None,
                 'board_power_W_mean': round(sum(w) / len(w), 1) if w else None, 'samples': len(mhz),
-                'peak_sclk_MHz': self.PEAK_SCLK_MHZ,
-                'source': 'amdgpu sysfs pp_dpm_sclk / %s' % (os.path.basename(self._power) if self._power else None)}
+                'peak_sclk_MHz': self.PEAK_SCLK_MHZ, 'source': 'rocm-smi --showclocks --showpower'}
 
 
 def time_steps(fn, sync, steps, warmup):
@@ -363,13 +358,11 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    with BoardSampler(local_rank) as board:
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        elapsed = time.perf_counter() - t0
-    board = board.summary()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
     # The timed region is short (K steps of ~3 ms) and starts right after the clock ramp: the board is still above the clock it
     # can SUSTAIN under its 1.4 kW cap.  A further untimed stretch of the same step gives the sustained figures the MFMA
     # fractions are also quoted against (`frac_at_sustained_sclk`), and the throughput at that point.
@@ -423,7 +416,7 @@ def main():
                         'frac': round(achieved / peak, 5), 'avg_launch_ms': round(ms, 5),
                         'launches_per_step': round(actual, 2) if actual != int(actual) else int(actual),
                         'share_of_device_time': round(ms * actual / dev_ms, 4) if dev_ms else None}
-        clk = (sustained or board).get('sclk_MHz_median')
+        clk = (sustained or {}).get('sclk_MHz_median')
         if bound == 'mfma' and clk:
             # the same fraction against the matrix peak AT THE CLOCK THE BOARD SUSTAINS under its power cap with this workload
             stages[name]['frac_at_sustained_sclk'] = round(achieved / (peak * clk / BoardSampler.PEAK_SCLK_MHZ), 5)
@@ -514,7 +507,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra:
         extra = extra_points(args, torch, np, koala_amd, model, kb, x, dx, dy, base, local_rank)
     # the constants the fractions are divided by, next to what a plain device-to-device copy reaches on this box
-    peaks = {'hbm_GBps': HBM_PEAK_GBS, 'mfma_TFLOPs': MFMA_PEAK_TFLOPS[args.precision], 'board_during_timed_region': board, 'board_sustained': sustained}
+    peaks = {'hbm_GBps': HBM_PEAK_GBS, 'mfma_TFLOPs': MFMA_PEAK_TFLOPS[args.precision], 'board_sustained': sustained}
     if rank == 0:
         src = torch.empty(1 << 30, dtype=torch.uint8, device='cuda')
         dst = torch.empty_like(src)

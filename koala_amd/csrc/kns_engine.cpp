@@ -260,6 +260,8 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     dev_synth_seg_ = dev_int("KOALA_AMD_SYNTH_SEG", 0);
     dev_small_mt_ = dev_int("KOALA_AMD_SMALL_MT", 0);
     dev_steps_mt_ = dev_int("KOALA_AMD_STEPS_MT", 192);
+    use_quad_ = dev_env("KOALA_AMD_NO_QUAD") == nullptr;  // A/B arm: input GEMM + recurrent kernel per layer instead of the fused one
+    quad_nb0_max_ = dev_int("KOALA_AMD_QUAD_NB0MAX", 2);
     // host-pointer calls are cut into sub-chunks of host_chunk_ frames (two staging slots = the Tmax-sized buffers)
     host_chunk_ = Tmax_ / 2 < 1 ? 1 : (Tmax_ / 2 > 16 ? 16 : Tmax_ / 2);
     host_pipeline_min_bytes_ = (size_t) 4 << 20;  // below this a call is launch-bound: sub-chunks would only add launches
@@ -355,6 +357,8 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     d_hseq_a_ = dalloc(M * nbh_ * 1024, true);
     d_hseq_b_ = dalloc(M * nbh_ * 1024, true);
     d_mask_ = (float *) dalloc(M * kMaskTiles * 1024, true);
+    d_xchg_ = dalloc(mtb * kQuadXchgBytesPerMtile, true);  // tags start at 0 = never valid
+    d_qerr_ = (unsigned *) dalloc(16, true);
     d_in_ = (int16_t *) dalloc((size_t) B_ * Tmax_ * kFrame * 2, true);
     d_out_ = (int16_t *) dalloc((size_t) B_ * Tmax_ * kFrame * 2, true);
     if (alloc_failed_) {
@@ -458,6 +462,27 @@ bool Engine::profile_read(double *ms, int64_t *launches, std::string *err) {
 bool Engine::synchronize(std::string *err) {
     if (hipStreamSynchronize(stream_) != hipSuccess) {
         *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
+        return false;
+    }
+    return check_quad_error(err);
+}
+
+// The fused layer kernel's waits are bounded: a workgroup that runs out of patience records a code and leaves, and the
+// results of that call are garbage.  The word is read back wherever the host waits for the stream anyway.
+bool Engine::check_quad_error(std::string *err) {
+    if (!quad_used_) return true;
+    quad_used_ = false;
+    unsigned code[4] = {0, 0, 0, 0};
+    if (hipMemcpyAsync(code, d_qerr_, sizeof(code), hipMemcpyDeviceToHost, stream_) != hipSuccess ||
+        hipStreamSynchronize(stream_) != hipSuccess) {
+        *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
+        return false;
+    }
+    if (code[0] != 0) {
+        char msg[160];
+        snprintf(msg, sizeof(msg), "fused GRU layer kernel gave up waiting (code 0x%08x): results of the call are invalid", code[0]);
+        *err = msg;
+        (void) hipMemsetAsync(d_qerr_, 0, 16, stream_);
         return false;
     }
     return true;
@@ -614,6 +639,35 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         tock(kClsGru);
     };
 
+    // Chunked bf16 calls whose m-tiles come in whole quads: a GRU layer is ONE launch (kns_gruq.hip) -- input GEMM, recurrent
+    // GEMM and gates fused over CU quads, no pre-activation round trip through HBM.  Same arithmetic as the two-kernel form,
+    // bit for bit (tests/test_gpu_parity.py::test_alternative_kernels_give_identical_pcm).
+    const bool quad = use_quad_ && !small && !small_steps && T >= 2 && T < 4096;
+    auto gru_quad = [&](const void *a0, int nb0, const void *a1, const void *wih, const float *bih, const void *whh,
+                        const float *bhh, int layer, void *hseq) {
+        GruQuadArgs g;
+        g.a0 = a0;
+        g.a1 = a1;
+        g.wih = wih;
+        g.bih = bih;
+        g.whh = whh;
+        g.bhh = bhh;
+        g.hstate_in = d_hstate_[hs_cur_] + (size_t) layer * mtb * kUnitTiles * 256;
+        g.hstate_out = d_hstate_[hs_cur_ ^ 1] + (size_t) layer * mtb * kUnitTiles * 256;
+        g.hseq = hseq;
+        g.xchg = d_xchg_;
+        g.err = d_qerr_;
+        g.nb0 = nb0;
+        g.T = T;
+        g.mtiles = mtb;
+        quad_serial_ = quad_serial_ >= (1u << 20) - 1 ? 1 : quad_serial_ + 1;
+        g.serial = quad_serial_;
+        quad_used_ = true;
+        tick(kClsGru);
+        if (only < 0 || only == kClsGru) launch_gru_quad(g, stream_);
+        tock(kClsGru);
+    };
+
     // front-end: e = features . W_in + b_in
     gemm(kClsGemmHead, nullptr, 0, d_feat_, nbf_, w_in_, b_in_, d_e_, nbh_ * pi_.npb, kHidden, kOutAPlain);
     for (int s = 0; s < kStages; ++s) {
@@ -628,10 +682,18 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
             for (int t = 0; t < T; ++t)
                 gru_small(nullptr, 0, d_hseq_a_, d.w_ih_b, d.b_ih_b, d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_, t);
         } else {
-            gemm(kClsGemmIn, yprev, nby, d_e_, nbh_, d.w_ih_a, d.b_ih_a, d_gi_, kGateTiles, 3 * kHidden, kOutGi);
-            gru(d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_);
-            gemm(kClsGemmIn, nullptr, 0, d_hseq_a_, nbh_, d.w_ih_b, d.b_ih_b, d_gi_, kGateTiles, 3 * kHidden, kOutGi);
-            gru(d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_);
+            if (quad && nby <= quad_nb0_max_ && gru_quad_supported(prec_, mtb, nby)) {
+                gru_quad(yprev, nby, d_e_, d.w_ih_a, d.b_ih_a, d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_);
+            } else {
+                gemm(kClsGemmIn, yprev, nby, d_e_, nbh_, d.w_ih_a, d.b_ih_a, d_gi_, kGateTiles, 3 * kHidden, kOutGi);
+                gru(d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_);
+            }
+            if (quad && gru_quad_supported(prec_, mtb, 0)) {
+                gru_quad(nullptr, 0, d_hseq_a_, d.w_ih_b, d.b_ih_b, d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_);
+            } else {
+                gemm(kClsGemmIn, nullptr, 0, d_hseq_a_, nbh_, d.w_ih_b, d.b_ih_b, d_gi_, kGateTiles, 3 * kHidden, kOutGi);
+                gru(d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_);
+            }
         }
         if (s < kStages - 1)
             gemm(kClsGemmHead, nullptr, 0, d_hseq_b_, nbh_, d.w_head, d.b_head, d_y_[s], d.head_tiles, d.head_dim,
@@ -780,8 +842,9 @@ bool Engine::process_host_pipelined(int T, const int16_t *pcm, int16_t *out, boo
     if (!ok) {
         *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
         (void) hipDeviceSynchronize();
+        return false;
     }
-    return ok;
+    return check_quad_error(err);
 }
 
 bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err, bool host_pointers) {
@@ -853,6 +916,7 @@ bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err, 
     if (!run_device(T, d_in_, d_out_, err)) return false;
     if (hipMemcpyAsync(h_out_, d_out_, bytes, hipMemcpyDeviceToHost, stream_) != hipSuccess) goto fail;
     if (hipStreamSynchronize(stream_) != hipSuccess) goto fail;
+    if (!check_quad_error(err)) return false;
     memcpy(out, h_out_, bytes);
     return true;
 fail:

@@ -102,6 +102,13 @@ private:
     bool use_graph_ = true, no_small_ = false, no_zero_copy_ = false, no_recompute_ = false, debug_taps_ = false;
     // developer switches (all read once in init() through dev_env(): compiled out of the product library)
     int dev_variant_ = 0, dev_only_class_ = -1, dev_analysis_seg_ = 0, dev_synth_seg_ = 0, dev_small_mt_ = 0, dev_steps_mt_ = 192;
+    // fused GRU layers over CU quads (kns_gruq.hip): granule exchange buffer, device error words, launch serial (tag bits)
+    void *d_xchg_ = nullptr;
+    unsigned *d_qerr_ = nullptr;
+    unsigned quad_serial_ = 0;
+    bool use_quad_ = true, quad_used_ = false;
+    int quad_nb0_max_ = 2;
+    bool check_quad_error(std::string *err);
     bool spec_valid_ = false;  // the last run_device() stored the spectrum (debug_read(1) refuses otherwise)
 
     // profiling

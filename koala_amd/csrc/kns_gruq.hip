@@ -1,0 +1,537 @@
+// kns_gruq.hip -- a whole GRU layer (input GEMM + recurrent GEMM + gates) over T frames in one launch,
+// fused over CU QUADS: the pre-activations x . W_ih never leave the CU (no `gi` round trip through HBM), and a CU works on
+// four independent m-tiles per step instead of being one in-order chain over a single one.
+//
+// Decomposition.  Four workgroups (same XCD by dispatch order: blocks b, b + 8, b + 16, b + 24) own four m-tiles = 64 streams.
+// Workgroup c keeps, for ALL T steps, the columns of W_ih and W_hh of hidden units 64 c .. 64 c + 63 (unit tiles 4 c .. 4 c + 3
+// = k-blocks 2 c, 2 c + 1 of the hidden state) in registers; unit tile 16 (units 256 .. 270) is kept by every workgroup and
+// served by workgroup c for m-tile c.  A "block" is (step t, m-tile m), walked in the order b = 4 t + m by everybody.
+//   x waves 0..3  wave j: W_ih of unit tile 4 c + j (3 x NBX fragments).  Per block: the 3 x NBX MFMAs of x_t . W_ih for that tile,
+//                 + b_ih, rounded to fp16 (the storage type of the unfused path's `gi`, so the arithmetic is the same bit for
+//                 bit), into a 4-deep LDS ring for its partner h wave.  They do not depend on h: they run up to 4 blocks ahead
+//                 and their MFMAs fill the matrix pipe while the partner's gate VALU work runs.  They also stage x_t in LDS
+//                 (each wave fetches a quarter of the k-blocks one block ahead).  Wave 3 also serves unit tile 16: its input
+//                 projection in the blocks with m = c (weights from LDS) and its gate math.
+//   h waves 4..7  wave j: W_hh of unit tile 4 c + j (27 fragments).  Per block: wait for h_{t-1} of the m-tile to be complete in
+//                 LDS, 27 MFMAs (waves 0..2: + one gate of tile 16 when m = c, weights from LDS), gates, h_t of its tile -> the
+//                 m-tile's LDS image (once every wave has finished READING it), -> the other three workgroups as granules, ->
+//                 the hidden sequence in HBM (the next kernel's A operand).  Before a block's MFMAs it requests the granules
+//                 the NEXT block needs from one of the other workgroups; after its gates it checks their tags and files them
+//                 into the LDS image (re-polling only if they were late).
+// Hand-off (MI355X guide, "R2"): a lane's 16-byte store carries two self-tagged 8-byte granules {tag, 2 x bf16}; tag = launch
+// serial << 12 | step + 1.  No flag, no fence, no drain: the data is its own flag; stores write through (sc1), loads bypass L1
+// (sc1).  Slots alternate with the step's parity; a slot is rewritten only after every consumer has used it (by data flow:
+// producing h_{t+2} needs all of h_{t+1}, which needed every consumer's h_t to be complete).
+// Synchronisation inside a workgroup: monotonic block counters in LDS, written and polled with explicit ds instructions (a
+// wave's DS operations execute in order: whoever sees a counter sees the data written before it); no barrier in the loop.
+// Every wait is bounded: on overrun the workgroup raises an abort word, records a code in GruQuadArgs::err and leaves.
+#include "kns_device.hpp"
+
+#include <limits.h>
+
+#include <type_traits>
+
+namespace kns {
+
+constexpr int kQWaves = 8;
+constexpr int kQDG = 4;                               // depth of the pre-activation rings, in blocks
+constexpr int kQHsBytes = 9 * 1024;                   // one hidden-state operand image: 9 k-blocks in A-fragment order
+constexpr int kQOffHs = 0;                            // [4 m-tiles]: h_{t-1} while a block reads it, then h_t tile by tile
+constexpr int kQOffXs = 4 * kQHsBytes;                // [2][NBX] KiB (sized for NBX = 11)
+constexpr int kQOffGi = kQOffXs + 2 * 11 * 1024;      // [4 pairs][kQDG][3 gates][64 lanes][8 B]
+constexpr int kQOffGh16 = kQOffGi + 4 * kQDG * 1536;  // [2][3][64][16 B]  unit tile 16: fp32 recurrent accumulators
+constexpr int kQOffW16x = kQOffGh16 + 2 * 3072;       // [3 gates][NBX] KiB  unit tile 16's W_ih (sized for NBX = 11)
+constexpr int kQOffW16h = kQOffW16x + 3 * 11 * 1024;  // [3 gates][9] KiB    unit tile 16's W_hh
+constexpr int kQOffFlags = kQOffW16h + 27 * 1024;     // 32 words
+constexpr int kQLds = kQOffFlags + 128;
+
+// flag words (all count blocks or steps upwards from 0)
+enum {
+    kFXW = 0,     // [4] x wave j has staged its share of x for blocks < value
+    kFGI = 4,     // [4] x wave j has produced the pre-activations of blocks < value
+    kFGC = 8,     // [4] h wave j has consumed the pre-activations of blocks < value
+    kFHL = 12,    // [4] h wave j has written its tile of h for blocks < value
+    kFHG = 16,    // [4] h wave j has filed the remote tiles it is responsible for, for the h that blocks < value READ
+    kFHM = 20,    // [4] h wave j has finished READING the operand images (its MFMAs) of blocks < value
+    kFH16 = 28,   //     unit tile 16 of h (m-tile c) is complete for steps < value
+    kFGH16 = 24,  // [3] gate j of unit tile 16's recurrent accumulators is there for steps < value
+    kFG16C = 27,  //     unit tile 16's gate math has consumed steps < value
+    kFAbort = 31,
+};
+
+constexpr int kQSpinLimit = 1 << 21;     // LDS polls (~0.2 s)
+constexpr int kQGatherLimit = 1 << 18;   // global polls (~0.3 s)
+
+__device__ __forceinline__ int q_flags_read(unsigned addr) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void q_flag_write(unsigned addr, int v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
+struct QCtx {
+    char *smem;
+    unsigned flags;       // LDS address of flag word 0
+    unsigned flags_lane;  // LDS address of flag word (lane & 31)
+    unsigned *err;
+    int lane, lane5, colq;
+    int c;                // workgroup's place in its quad
+    int mt0;              // first m-tile of the quad
+    int T, mtiles, NB;    // NB = 4 T blocks
+    unsigned tag_base;
+    bool even;            // lane holds an even column of its unit tile
+    int lane_off;         // byte offset of this lane's first packed word inside a unit tile's half k-block (second: + 16)
+};
+
+__device__ __forceinline__ void q_abort(const QCtx &cx, unsigned code) {
+    q_flag_write(cx.flags + kFAbort * 4, 1);
+    if (cx.lane == 0) atomicCAS(cx.err, 0u, code);
+}
+
+// waits until flag[i] >= need(i) for every word (need is this lane's requirement for word lane & 31; INT_MIN = none)
+__device__ __forceinline__ bool q_wait(const QCtx &cx, int need, unsigned code) {
+    for (int spin = 0;; ++spin) {
+        const int v = q_flags_read(cx.flags_lane);
+        if (__builtin_amdgcn_readlane(v, kFAbort) != 0) return false;
+        if (__builtin_amdgcn_ballot_w64(v < need) == 0) return true;
+        if (spin > kQSpinLimit) {
+            q_abort(cx, code);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// a unit tile of h in C-fragment order (lane: column colq, rows 4 q .. 4 q + 3) -> this lane's two packed words of the A
+// operand: neighbouring lanes trade two values so that a word holds two consecutive k of one row
+__device__ __forceinline__ void q_pack(const f32x4 &h, bool even, unsigned &w0, unsigned &w1) {
+    const float s0 = even ? h[2] : h[0], s1 = even ? h[3] : h[1];
+    const float r0 = lane_pair(s0), r1 = lane_pair(s1);
+    const float lo0 = even ? h[0] : r0, hi0 = even ? r0 : h[2];
+    const float lo1 = even ? h[1] : r1, hi1 = even ? r1 : h[3];
+    w0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo0, hi0}, bf16x2));
+    w1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo1, hi1}, bf16x2));
+}
+__device__ __forceinline__ int q_tile_off(int u) { return (u >> 1) * 1024 + (u & 1) * 512; }
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// the bf16 configuration's gate arithmetic -- operation for operation what gru_resident8_kernel does
+__device__ __forceinline__ f32x4 q_gates(const f32x4 (&acc)[3], u32x2 pr, u32x2 pz, u32x2 pn, float br, float bz, float bn,
+                                         const f32x4 &hprev) {
+    const f32x2 vbr = {br, br}, vbz = {bz, bz}, vbn = {bn, bn};
+    f32x4 hnew;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const f32x2 ar = {acc[0][2 * p], acc[0][2 * p + 1]}, az = {acc[1][2 * p], acc[1][2 * p + 1]},
+                    an = {acc[2][2 * p], acc[2][2 * p + 1]};
+        const f32x2 tr = ar + vbr, tz = az + vbz, tn = an + vbn;
+        const f32x2 r = fast_sigmoid2(f32x2{mix_add<0>(pr[p], tr[0]), mix_add<1>(pr[p], tr[1])});
+        const f32x2 z = fast_sigmoid2(f32x2{mix_add<0>(pz[p], tz[0]), mix_add<1>(pz[p], tz[1])});
+        const f32x2 n = fast_tanh2(f32x2{mix_fma<0>(r[0], tn[0], pn[p]), mix_fma<1>(r[1], tn[1], pn[p])});
+        const f32x2 hp = {hprev[2 * p], hprev[2 * p + 1]};
+        const f32x2 h = gate_fma2(z, hp - n, n);
+        hnew[2 * p] = h[0];
+        hnew[2 * p + 1] = h[1];
+    }
+    return hnew;
+}
+
+// h_t of unit tile u, m-tile (local) m: own LDS image, granules for the other workgroups, hidden sequence in HBM
+__device__ __forceinline__ void q_publish(const GruQuadArgs &g, const QCtx &cx, int t, int m, int u, const f32x4 &hnew) {
+    unsigned w0, w1;
+    q_pack(hnew, cx.even, w0, w1);
+    char *img = cx.smem + kQOffHs + m * kQHsBytes + q_tile_off(u) + cx.lane_off;
+    *(unsigned *) img = w0;
+    *(unsigned *) (img + 16) = w1;
+    const int mt = cx.mt0 + m;
+    const unsigned tag = cx.tag_base | (unsigned) (t + 1);
+    const __amdgpu_buffer_rsrc_t gr =
+        make_rsrc((char *) g.xchg + (((size_t) mt * 2 + (t & 1)) * 17 + u) * 1024, 1024);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{tag, w0, tag, w1}, gr, cx.lane * 16u, 0, 16 /* sc1: write through */);
+    char *hs = (char *) g.hseq + ((size_t) t * cx.mtiles + mt) * kQHsBytes + q_tile_off(u) + cx.lane_off;
+    *(unsigned *) hs = w0;
+    *(unsigned *) (hs + 16) = w1;
+}
+
+// ------------------------------------------------------------------------------------------------ x waves
+
+// 3 x NBX MFMAs of one block against the wave's register-resident W_ih tile
+template <int NBX>
+__device__ __forceinline__ void q_x_mma(f32x4 (&acc)[3], const bf16x8 *xa, const bf16x8 (&w)[3][NBX], int lane) {
+    bf16x8 qa[2];
+    qa[0] = xa[lane];
+    qa[1] = xa[64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int blk = 0; blk < NBX; ++blk) {
+        const bf16x8 a = qa[blk & 1];
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt) acc[gt] = PBF16::mma(a, w[gt][blk], acc[gt]);
+        if (blk + 2 < NBX) qa[blk & 1] = xa[(blk + 2) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// the same for unit tile 16, whose weights live in LDS ([gate][k-block] fragments): a second pass over the staged x operand,
+// rolled so that it needs a handful of registers
+template <int NBX>
+__device__ __forceinline__ void q_x_mma16(f32x4 (&acc)[3], const bf16x8 *xa, const bf16x8 *w16, int lane) {
+#pragma nounroll
+    for (int blk = 0; blk < NBX; ++blk) {
+        const bf16x8 a = xa[blk * 64 + lane];
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt) acc[gt] = PBF16::mma(a, w16[(gt * NBX + blk) * 64 + lane], acc[gt]);
+    }
+}
+
+template <int NB0>
+__device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, const int j) {
+    typedef bf16x8 frag_t;
+    constexpr int NBX = 9 + NB0;
+    const int lane = cx.lane, c = cx.c, u = 4 * c + j;
+    const frag_t *wih = (const frag_t *) g.wih;
+    frag_t w[3][NBX];
+    float bi[3];
+#pragma unroll
+    for (int gt = 0; gt < 3; ++gt) {
+#pragma unroll
+        for (int blk = 0; blk < NBX; ++blk) w[gt][blk] = wih[((size_t) (u * 3 + gt) * NBX + blk) * 64 + lane];
+        bi[gt] = g.bih[(u * 3 + gt) * 16 + cx.colq];
+    }
+    const frag_t *w16 = (const frag_t *) (cx.smem + kQOffW16x);
+
+    // this wave's share of a block's x operand: k-blocks j, j + 4, j + 8 (clamped: an extra copy of the last one is harmless)
+    const int p0 = j, p1 = j + 4, p2 = j + 8 < NBX ? j + 8 : NBX - 1;
+    auto piece = [&](int blk, int i) -> const frag_t * {
+        const size_t mtg = (size_t) (blk >> 2) * cx.mtiles + cx.mt0 + (blk & 3);
+        if (NB0 > 0 && i < NB0) return (const frag_t *) g.a0 + (mtg * NB0 + i) * 64 + lane;
+        return (const frag_t *) g.a1 + (mtg * 9 + (i - NB0)) * 64 + lane;
+    };
+
+    u32x2 gi16[3] = {u32x2{0, 0}, u32x2{0, 0}, u32x2{0, 0}};  // (wave 3) unit tile 16's fp16 pre-activations of the current step
+    auto do_block = [&](const int b, auto w16_tag) {
+        constexpr bool kW16 = decltype(w16_tag)::value;
+        const int bn = b + 1 < cx.NB ? b + 1 : cx.NB - 1;
+        const frag_t s0 = *piece(bn, p0), s1 = *piece(bn, p1), s2 = *piece(bn, p2);  // in flight during the MFMAs
+        const frag_t *xa = (const frag_t *) (cx.smem + kQOffXs + (b & 1) * NBX * 1024);
+        f32x4 acc[3];
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        q_x_mma<NBX>(acc, xa, w, lane);
+        char *ring = cx.smem + kQOffGi + ((j * kQDG + (b & (kQDG - 1))) * 3) * 512 + lane * 8;
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt) {
+            f32x4 v = acc[gt];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = v[i] + bi[gt];
+            *(f16x4 *) (ring + gt * 512) = PBF16::to_gi(v);
+        }
+        q_flag_write(cx.flags + (kFGI + j) * 4, b + 1);
+        if (kW16) {
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            q_x_mma16<NBX>(acc, xa, w16, lane);
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt) {
+                const float b16 = g.bih[(16 * 3 + gt) * 16 + cx.colq];
+                f32x4 v = acc[gt];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = v[i] + b16;
+                gi16[gt] = __builtin_bit_cast(u32x2, PBF16::to_gi(v));
+            }
+        }
+        frag_t *xn = (frag_t *) (cx.smem + kQOffXs + ((b + 1) & 1) * NBX * 1024);
+        xn[p0 * 64 + lane] = s0;
+        xn[p1 * 64 + lane] = s1;
+        xn[p2 * 64 + lane] = s2;
+        q_flag_write(cx.flags + (kFXW + j) * 4, b + 2);
+    };
+
+    if (j < 3) {
+        for (int b = 0; b < cx.NB; ++b) {
+            // the x operand of this block is staged and the ring slot is free
+            const int need = cx.lane5 < 4 ? b + 1 : cx.lane5 == kFGC + j ? b + 1 - kQDG : INT_MIN;
+            if (!q_wait(cx, need, 0x10000000u | (unsigned) (j << 24) | (unsigned) b)) return;
+            do_block(b, std::false_type{});
+        }
+        return;
+    }
+
+    // ---- wave 3: its own blocks (with unit tile 16's input projection where m = c), and unit tile 16's gate math as soon as
+    // the h waves have delivered a step's recurrent accumulators -- whichever is ready, never blocking on one while the other
+    // could run
+    const float bh16r = g.bhh[(16 * 3 + 0) * 16 + cx.colq], bh16z = g.bhh[(16 * 3 + 1) * 16 + cx.colq],
+                bh16n = g.bhh[(16 * 3 + 2) * 16 + cx.colq];
+    f32x4 h16 = ((const f32x4 *) g.hstate_in)[((size_t) (cx.mt0 + c) * kUnitTiles + 16) * 64 + lane];
+    int b = 0, t16 = 0, spin = 0;
+    while (b < cx.NB || t16 < cx.T) {
+        const int v = q_flags_read(cx.flags_lane);
+        if (__builtin_amdgcn_readlane(v, kFAbort) != 0) return;
+        // gate math of step t16: this wave has been through block (t16, c) (gi16 holds that step), the three recurrent
+        // accumulators are in LDS, and h wave 3 too has finished reading the image the result goes into
+        const int b16 = 4 * t16 + c;
+        const bool late16 = (cx.lane5 >= kFGH16 && cx.lane5 < kFGH16 + 3) ? v < t16 + 1 : (cx.lane5 == kFHM + 3 ? v < b16 + 1 : false);
+        if (t16 < cx.T && b > b16 && __builtin_amdgcn_ballot_w64(late16) == 0) {
+            const int t = t16;
+            const char *gh = cx.smem + kQOffGh16 + (t & 1) * 3 * 1024 + lane * 16;
+            f32x4 acc[3];
+            acc[0] = *(const f32x4 *) gh;
+            acc[1] = *(const f32x4 *) (gh + 1024);
+            acc[2] = *(const f32x4 *) (gh + 2048);
+            q_flag_write(cx.flags + kFG16C * 4, t + 1);  // (behind the reads in this wave's DS queue)
+            h16 = q_gates(acc, gi16[0], gi16[1], gi16[2], bh16r, bh16z, bh16n, h16);
+            q_publish(g, cx, t, c, 16, h16);
+            q_flag_write(cx.flags + kFH16 * 4, t + 1);
+            ++t16;
+            spin = 0;
+            continue;
+        }
+        // next block: staged, ring slot free, and (m = c) the previous step's gi16 consumed
+        const bool late = cx.lane5 < 4 ? v < b + 1 : (cx.lane5 == kFGC + 3 ? v < b + 1 - kQDG : false);
+        const bool tile16 = (b & 3) == c;
+        if (b < cx.NB && (!tile16 || t16 >= (b >> 2)) && __builtin_amdgcn_ballot_w64(late) == 0) {
+            if (tile16)
+                do_block(b, std::true_type{});
+            else
+                do_block(b, std::false_type{});
+            ++b;
+            spin = 0;
+            continue;
+        }
+        if (++spin > kQSpinLimit) {
+            q_abort(cx, 0x13000000u | (unsigned) (b & 0xffff) | ((unsigned) (t16 & 0xff) << 16));
+            return;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    ((f32x4 *) g.hstate_out)[((size_t) (cx.mt0 + c) * kUnitTiles + 16) * 64 + lane] = h16;
+}
+
+// ------------------------------------------------------------------------------------------------ h waves
+
+// 27 MFMAs of one block against the wave's register-resident W_hh tile; kW16: one gate of unit tile 16 as a fourth chain,
+// its weights read from LDS through a two-deep queue
+template <bool kW16>
+__device__ __forceinline__ void q_h_mma(f32x4 (&acc)[3], f32x4 &a16, const bf16x8 *ha, const bf16x8 (&w)[27], const bf16x8 *w16,
+                                        int lane) {
+    bf16x8 qa[2], qw[2];
+    qa[0] = ha[lane];
+    qa[1] = ha[64 + lane];
+    if (kW16) {
+        qw[0] = w16[lane];
+        qw[1] = w16[64 + lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int blk = 0; blk < 9; ++blk) {
+        const bf16x8 a = qa[blk & 1];
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt) acc[gt] = PBF16::mma(a, w[blk * 3 + gt], acc[gt]);
+        if (kW16) a16 = PBF16::mma(a, qw[blk & 1], a16);
+        if (blk + 2 < 9) {
+            qa[blk & 1] = ha[(blk + 2) * 64 + lane];
+            if (kW16) qw[blk & 1] = w16[(blk + 2) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__device__ __forceinline__ void q_h_wave(const GruQuadArgs &g, const QCtx &cx, const int j) {
+    typedef bf16x8 frag_t;
+    const int lane = cx.lane, c = cx.c, u = 4 * c + j;
+    const frag_t *whh = (const frag_t *) g.whh;
+    frag_t w[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) w[i] = whh[((size_t) (u * 3 + i % 3) * 9 + i / 3) * 64 + lane];
+    const frag_t *w16 = (const frag_t *) (cx.smem + kQOffW16h) + (j < 3 ? j : 0) * 9 * 64;  // gate j of unit tile 16
+    const float br = g.bhh[(u * 3 + 0) * 16 + cx.colq], bz = g.bhh[(u * 3 + 1) * 16 + cx.colq], bn = g.bhh[(u * 3 + 2) * 16 + cx.colq];
+    f32x4 hreg[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) hreg[m] = ((const f32x4 *) g.hstate_in)[((size_t) (cx.mt0 + m) * kUnitTiles + u) * 64 + lane];
+
+    // Remote tiles this wave files into the LDS images: waves 0..2 the four tiles of workgroup (c + 1 + j) & 3, wave 3 unit
+    // tile 16 from the workgroup that serves it for the m-tile (none when that is this workgroup).
+    const int rq = (c + 1 + j) & 3;
+    auto gather_tile = [&](int i) { return j < 3 ? 4 * rq + i : 16; };
+    auto gather_load = [&](int bq, u32x4 (&gr)[4]) {  // the h that block bq READS: step (bq >> 2) - 1 of m-tile bq & 3
+        const int ts = (bq >> 2) - 1, mq = bq & 3;
+        const size_t slot = ((size_t) (cx.mt0 + mq) * 2 + (ts & 1)) * 17;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const __amdgpu_buffer_rsrc_t r = make_rsrc((const char *) g.xchg + (slot + gather_tile(i)) * 1024, 1024);
+            gr[i] = __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16u, 0, 16 /* sc1: from L2, never this CU's L1 */);
+        }
+    };
+
+    for (int b = 0; b < cx.NB; ++b) {
+        const int t = b >> 2, m = b & 3;
+        // ---- request what the next block reads (redirected to something harmless where there is nothing to get)
+        const int bq = b + 1;
+        const bool real = bq < cx.NB && (bq >> 2) >= 1 && (j < 3 || (bq & 3) != c);
+        u32x4 gr[4];
+        gather_load(real ? bq : 4 + m, gr);
+
+        // ---- this block's inputs: pre-activations, every tile of h_{t-1} (own workgroup's, filed remote ones, tile 16)
+        {
+            const int need = cx.lane5 == kFGI + j ? b + 1
+                             : (cx.lane5 >= kFHL && cx.lane5 < kFHL + 4) ? b - 3
+                             : (cx.lane5 >= kFHG && cx.lane5 < kFHG + 4) ? b + 1
+                             : (cx.lane5 == kFH16 && m == c) ? t
+                             : (cx.lane5 == kFG16C && m == c && j < 3) ? t - 1
+                                                                       : INT_MIN;
+            if (!q_wait(cx, need, 0x20000000u | (unsigned) (j << 24) | (unsigned) b)) return;
+        }
+        const frag_t *ha = (const frag_t *) (cx.smem + kQOffHs + m * kQHsBytes);  // holds h_{t-1} now
+        f32x4 acc[3], a16 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool with16 = (m == c) && (j < 3);
+        if (with16)
+            q_h_mma<true>(acc, a16, ha, w, w16, lane);
+        else
+            q_h_mma<false>(acc, a16, ha, w, w16, lane);
+        q_flag_write(cx.flags + (kFHM + j) * 4, b + 1);  // (behind this block's operand reads in the wave's DS queue)
+        if (with16) {
+            *(f32x4 *) (cx.smem + kQOffGh16 + ((t & 1) * 3 + j) * 1024 + lane * 16) = a16;
+            q_flag_write(cx.flags + (kFGH16 + j) * 4, t + 1);
+        }
+        const char *ring = cx.smem + kQOffGi + ((j * kQDG + (b & (kQDG - 1))) * 3) * 512 + lane * 8;
+        const u32x2 pr = *(const u32x2 *) ring, pz = *(const u32x2 *) (ring + 512), pn = *(const u32x2 *) (ring + 1024);
+        q_flag_write(cx.flags + (kFGC + j) * 4, b + 1);  // (behind the three reads in this wave's DS queue)
+        // (m is a runtime value: select the register, do not index the array)
+        const f32x4 hprev = m == 0 ? hreg[0] : m == 1 ? hreg[1] : m == 2 ? hreg[2] : hreg[3];
+        const f32x4 hnew = q_gates(acc, pr, pz, pn, br, bz, bn, hprev);
+        if (m == 0) hreg[0] = hnew;
+        if (m == 1) hreg[1] = hnew;
+        if (m == 2) hreg[2] = hnew;
+        if (m == 3) hreg[3] = hnew;
+        // the image is rewritten in place: every h wave must be through with reading h_{t-1}
+        {
+            const int need = (cx.lane5 >= kFHM && cx.lane5 < kFHM + 4) ? b + 1 : INT_MIN;
+            if (!q_wait(cx, need, 0x28000000u | (unsigned) (j << 24) | (unsigned) b)) return;
+        }
+        q_publish(g, cx, t, m, u, hnew);
+        q_flag_write(cx.flags + (kFHL + j) * 4, b + 1);
+
+        // ---- file the remote tiles the next block reads (its image was last read by block bq - 4 <= b: see the wait above)
+        if (real) {
+            const unsigned tag = cx.tag_base | (unsigned) (bq >> 2);  // step (bq >> 2) - 1, + 1
+            for (int spin = 0;; ++spin) {
+                bool ok = true;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ok = ok && gr[i][0] == tag && gr[i][2] == tag;
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                const int v = q_flags_read(cx.flags_lane);
+                if (__builtin_amdgcn_readlane(v, kFAbort) != 0) return;
+                if (spin > kQGatherLimit) {
+                    q_abort(cx, 0x30000000u | (unsigned) (j << 24) | (unsigned) bq);
+                    return;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                asm volatile("" ::: "memory");
+                gather_load(bq, gr);
+            }
+            char *img = cx.smem + kQOffHs + (bq & 3) * kQHsBytes + cx.lane_off;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *(unsigned *) (img + q_tile_off(gather_tile(i))) = gr[i][1];
+                *(unsigned *) (img + q_tile_off(gather_tile(i)) + 16) = gr[i][3];
+            }
+        }
+        if (bq >= 4) q_flag_write(cx.flags + (kFHG + j) * 4, bq + 1);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) ((f32x4 *) g.hstate_out)[((size_t) (cx.mt0 + m) * kUnitTiles + u) * 64 + lane] = hreg[m];
+}
+
+// ------------------------------------------------------------------------------------------------ kernel
+
+template <int NB0>
+__global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad_kernel(GruQuadArgs g) {
+    constexpr int NBX = 9 + NB0;
+    __shared__ __attribute__((aligned(16))) char smem[kQLds];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x;
+    const int nquads = g.mtiles >> 2;
+
+    QCtx cx;
+    cx.smem = smem;
+    cx.flags = (unsigned) (uintptr_t) (smem + kQOffFlags);
+    cx.flags_lane = cx.flags + (lane & 31) * 4;
+    cx.err = g.err;
+    cx.lane = lane;
+    cx.lane5 = lane & 31;
+    cx.colq = lane & 15;
+    cx.c = (bid >> 3) & 3;
+    cx.T = g.T;
+    cx.mtiles = g.mtiles;
+    cx.NB = 4 * g.T;
+    cx.tag_base = g.serial << 12;
+    cx.even = (lane & 1) == 0;
+    {
+        const int row0 = (lane >> 4) * 4 + (cx.even ? 0 : 2), kk0 = cx.colq & ~1;
+        cx.lane_off = (row0 + 16 * (kk0 >> 3)) * 16 + (kk0 & 7) * 2;
+    }
+    // one quad per four workgroups: blocks b, b + 8, b + 16, b + 24 of a group of 32 (one XCD by dispatch order).  Larger
+    // batches are covered by further launches (launch_gru_quad), so every workgroup of a launch is resident at once and a
+    // quad never waits for a workgroup that has not been dispatched.
+    const int qq = g.quad0 + (bid >> 5) * 8 + (bid & 7);
+    if (qq >= nquads) return;
+    cx.mt0 = 4 * qq;
+
+    // ---- prologue: unit tile 16's weights (LDS-resident for the whole launch), zeroed operand images (k-block 8's upper half
+    // stays zero for good), counters, initial h, block 0's x
+    for (int i = wave; i < 3 * NBX; i += kQWaves)
+        ((bf16x8 *) (smem + kQOffW16x))[i * 64 + lane] = ((const bf16x8 *) g.wih)[((size_t) 48 * NBX + i) * 64 + lane];
+    for (int i = wave; i < 27; i += kQWaves)
+        ((bf16x8 *) (smem + kQOffW16h))[i * 64 + lane] = ((const bf16x8 *) g.whh)[((size_t) 48 * 9 + i) * 64 + lane];
+    for (int i = tid; i < 4 * kQHsBytes / 16; i += 64 * kQWaves) ((uint4 *) (smem + kQOffHs))[i] = uint4{0, 0, 0, 0};
+    if (tid < 32) ((int *) (smem + kQOffFlags))[tid] = (tid >= kFHG && tid < kFHG + 4) ? 4 : 0;
+    __syncthreads();
+    for (int idx = wave; idx < 4 * kUnitTiles; idx += kQWaves) {
+        const int m = idx / kUnitTiles, u = idx % kUnitTiles;
+        const f32x4 hv = ((const f32x4 *) g.hstate_in)[((size_t) (cx.mt0 + m) * kUnitTiles + u) * 64 + lane];
+        unsigned w0, w1;
+        q_pack(hv, cx.even, w0, w1);
+        char *img = smem + kQOffHs + m * kQHsBytes + q_tile_off(u) + cx.lane_off;  // h_{-1}
+        *(unsigned *) img = w0;
+        *(unsigned *) (img + 16) = w1;
+    }
+    for (int i = wave; i < NBX; i += kQWaves) {
+        const bf16x8 *src = i < NB0 ? (const bf16x8 *) g.a0 + ((size_t) cx.mt0 * NB0 + i) * 64
+                                    : (const bf16x8 *) g.a1 + ((size_t) cx.mt0 * 9 + (i - NB0)) * 64;
+        ((bf16x8 *) (smem + kQOffXs))[i * 64 + lane] = src[lane];
+    }
+    if (tid < 4) ((int *) (smem + kQOffFlags))[kFXW + tid] = 1;
+    __syncthreads();
+    if (wave < 4)
+        q_x_wave<NB0>(g, cx, wave);
+    else
+        q_h_wave(g, cx, wave - 4);
+}
+
+bool gru_quad_supported(int precision, int mtiles, int nb0) {
+    return precision == kBf16 && mtiles >= 4 && mtiles % 4 == 0 && nb0 >= 0 && nb0 <= 2;
+}
+
+void launch_gru_quad(const GruQuadArgs &a, hipStream_t s) {
+    const int nquads = a.mtiles / 4;
+    for (int q0 = 0; q0 < nquads; q0 += 64) {  // 64 quads = 256 workgroups = one per CU
+        GruQuadArgs g = a;
+        g.quad0 = q0;
+        const int n = nquads - q0 < 64 ? nquads - q0 : 64;
+        const dim3 grid((n + 7) / 8 * 32), block(64 * kQWaves);  // 32 workgroups = 8 quads, one per XCD
+        if (a.nb0 == 0)
+            hipLaunchKernelGGL(gru_quad_kernel<0>, grid, block, 0, s, g);
+        else if (a.nb0 == 1)
+            hipLaunchKernelGGL(gru_quad_kernel<1>, grid, block, 0, s, g);
+        else
+            hipLaunchKernelGGL(gru_quad_kernel<2>, grid, block, 0, s, g);
+    }
+}
+
+}  // namespace kns

@@ -105,6 +105,32 @@ struct GruSmallArgs {
 };
 void launch_gru_small(const GruSmallArgs &a, hipStream_t s);
 
+// ---- a whole GRU layer over T frames in ONE launch: input GEMM + recurrent GEMM + gates fused over CU quads (kns_gruq.hip).
+// Four workgroups on one XCD own four m-tiles (64 streams); workgroup c keeps the columns of W_ih AND W_hh that belong to
+// hidden units 64 c .. 64 c + 63 resident in registers (every workgroup also keeps unit tile 16 and serves it for m-tile c),
+// computes its quarter of h' for all four m-tiles per step, and the quarters cross through L2 as self-tagged 8-byte granules.
+// The pre-activations never leave the CU: no `gi` round trip through HBM.
+struct GruQuadArgs {
+    const void *a0;     // A-packed y_prev [T * mtiles][nb0] (null when nb0 == 0)
+    const void *a1;     // A-packed e or the previous layer's hidden sequence [T * mtiles][9]
+    const void *wih;    // B-packed [51][nb0 + 9]
+    const float *bih;   // [51 * 16]
+    const void *whh;    // B-packed [51][9]
+    const float *bhh;   // [51 * 16]
+    const float *hstate_in;   // C-packed fp32 [mtiles][17][64][4]
+    float *hstate_out;
+    void *hseq;         // A-packed [T][mtiles][9], out
+    void *xchg;         // granule exchange buffer [mtiles][2][17][64][16 B]: {tag, 2 x bf16, tag, 2 x bf16} per lane
+    unsigned *err;      // [4] device words: first failure code of a launch (0 = none), see kns_gruq.hip
+    int nb0, T, mtiles;
+    unsigned serial;    // launch serial number (the high bits of every granule tag of this launch); never 0
+    int quad0 = 0;      // first quad of this launch (set by launch_gru_quad: 64 quads per launch)
+};
+// true when the shape is one the fused kernel takes (bf16, T >= 1, m-tiles in whole quads)
+bool gru_quad_supported(int precision, int mtiles, int nb0);
+void launch_gru_quad(const GruQuadArgs &a, hipStream_t s);
+constexpr size_t kQuadXchgBytesPerMtile = 2 * 17 * 1024;
+
 // ---- state reset of selected streams
 struct ResetArgs {
     int16_t *hist;   // [Bpad][256] (both ping-pong copies are cleared)
