@@ -262,6 +262,7 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     dev_steps_mt_ = dev_int("KOALA_AMD_STEPS_MT", 192);
     use_quad_ = dev_env("KOALA_AMD_NO_QUAD") == nullptr;  // A/B arm: input GEMM + recurrent kernel per layer instead of the fused one
     quad_nb0_max_ = dev_int("KOALA_AMD_QUAD_NB0MAX", 2);
+    qdbg_block_ = dev_int("KOALA_AMD_QUAD_DBG", -1);
     // host-pointer calls are cut into sub-chunks of host_chunk_ frames (two staging slots = the Tmax-sized buffers)
     host_chunk_ = Tmax_ / 2 < 1 ? 1 : (Tmax_ / 2 > 16 ? 16 : Tmax_ / 2);
     host_pipeline_min_bytes_ = (size_t) 4 << 20;  // below this a call is launch-bound: sub-chunks would only add launches
@@ -359,6 +360,7 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     d_mask_ = (float *) dalloc(M * kMaskTiles * 1024, true);
     d_xchg_ = dalloc(mtb * kQuadXchgBytesPerMtile, true);  // tags start at 0 = never valid
     d_qerr_ = (unsigned *) dalloc(16, true);
+    if (qdbg_block_ >= 0) d_qdbg_ = (unsigned long long *) dalloc((size_t) 8 * 4 * Tmax_ * 8 * 8, true);
     d_in_ = (int16_t *) dalloc((size_t) B_ * Tmax_ * kFrame * 2, true);
     d_out_ = (int16_t *) dalloc((size_t) B_ * Tmax_ * kFrame * 2, true);
     if (alloc_failed_) {
@@ -662,6 +664,8 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         g.mtiles = mtb;
         quad_serial_ = quad_serial_ >= (1u << 20) - 1 ? 1 : quad_serial_ + 1;
         g.serial = quad_serial_;
+        g.dbg = d_qdbg_;
+        g.dbg_block = qdbg_block_;
         quad_used_ = true;
         tick(kClsGru);
         if (only < 0 || only == kClsGru) launch_gru_quad(g, stream_);
@@ -1012,6 +1016,19 @@ int64_t Engine::debug_read(int what, float *out, int64_t capacity, std::string *
                 for (int k = 0; k < kHidden; ++k)
                     out[((size_t) l * B_ + b) * kHidden + k] =
                         s[(((size_t) l * mtb + b / 16) * kUnitTiles + k / 16) * 256 + cpack_off(b % 16, k % 16)];
+    } else if (what == 5) {  // developer build: stamps of the last fused layer launch, [8 waves][4 T][8] ticks since the first one
+        if (!d_qdbg_) {
+            *err = "no stamps: developer build with KOALA_AMD_QUAD_DBG=<workgroup>";
+            return -1;
+        }
+        n = (int64_t) 8 * 4 * T * 8;
+        if (n > capacity) return -2;
+        auto h = fetch(d_qdbg_, (size_t) n * 8);
+        const unsigned long long *st = (const unsigned long long *) h.data();
+        unsigned long long t0 = ~0ull;
+        for (int64_t i = 0; i < n; ++i)
+            if (i % 8 != 7 && st[i] && st[i] < t0) t0 = st[i];
+        for (int64_t i = 0; i < n; ++i) out[i] = i % 8 == 7 ? (float) st[i] : (st[i] ? (float) (st[i] - t0) : -1.0f);
     } else {
         *err = "unknown debug tap";
         return -1;

@@ -109,6 +109,8 @@ private:
     bool use_quad_ = true, quad_used_ = false;
     int quad_nb0_max_ = 2;
     bool check_quad_error(std::string *err);
+    unsigned long long *d_qdbg_ = nullptr;  // developer build, KOALA_AMD_QUAD_DBG=<block>: stamps of the LAST fused launch
+    int qdbg_block_ = -1;
     bool spec_valid_ = false;  // the last run_device() stored the spectrum (debug_read(1) refuses otherwise)
 
     // profiling

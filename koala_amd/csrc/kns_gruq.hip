@@ -72,6 +72,7 @@ __device__ __forceinline__ void q_flag_write(unsigned addr, int v) {
 }
 
 struct QCtx {
+    unsigned long long *dbg;  // this wave's stamp rows ([block][8]) or null
     char *smem;
     unsigned flags;       // LDS address of flag word 0
     unsigned flags_lane;  // LDS address of flag word (lane & 31)
@@ -84,6 +85,14 @@ struct QCtx {
     bool even;            // lane holds an even column of its unit tile
     int lane_off;         // byte offset of this lane's first packed word inside a unit tile's half k-block (second: + 16)
 };
+
+// developer instrumentation: s_memtime of one workgroup's waves at fixed points of every block (null in production)
+__device__ __forceinline__ void q_stamp(const QCtx &cx, int b, int slot) {
+    if (cx.dbg && cx.lane == 0) cx.dbg[b * 8 + slot] = __builtin_amdgcn_s_memtime();
+}
+__device__ __forceinline__ void q_note(const QCtx &cx, int b, int slot, unsigned long long v) {
+    if (cx.dbg && cx.lane == 0) cx.dbg[b * 8 + slot] = v;
+}
 
 __device__ __forceinline__ void q_abort(const QCtx &cx, unsigned code) {
     q_flag_write(cx.flags + kFAbort * 4, 1);
@@ -221,6 +230,7 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
 #pragma unroll
         for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
         q_x_mma<NBX>(acc, xa, w, lane);
+        q_stamp(cx, b, 2);
         char *ring = cx.smem + kQOffGi + ((j * kQDG + (b & (kQDG - 1))) * 3) * 512 + lane * 8;
 #pragma unroll
         for (int gt = 0; gt < 3; ++gt) {
@@ -254,8 +264,11 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
         for (int b = 0; b < cx.NB; ++b) {
             // the x operand of this block is staged and the ring slot is free
             const int need = cx.lane5 < 4 ? b + 1 : cx.lane5 == kFGC + j ? b + 1 - kQDG : INT_MIN;
+            q_stamp(cx, b, 0);
             if (!q_wait(cx, need, 0x10000000u | (unsigned) (j << 24) | (unsigned) b)) return;
+            q_stamp(cx, b, 1);
             do_block(b, std::false_type{});
+            q_stamp(cx, b, 3);
         }
         return;
     }
@@ -282,9 +295,11 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
             acc[1] = *(const f32x4 *) (gh + 1024);
             acc[2] = *(const f32x4 *) (gh + 2048);
             q_flag_write(cx.flags + kFG16C * 4, t + 1);  // (behind the reads in this wave's DS queue)
+            q_stamp(cx, b16, 4);
             h16 = q_gates(acc, gi16[0], gi16[1], gi16[2], bh16r, bh16z, bh16n, h16);
             q_publish(g, cx, t, c, 16, h16);
             q_flag_write(cx.flags + kFH16 * 4, t + 1);
+            q_stamp(cx, b16, 5);
             ++t16;
             spin = 0;
             continue;
@@ -293,10 +308,12 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
         const bool late = cx.lane5 < 4 ? v < b + 1 : (cx.lane5 == kFGC + 3 ? v < b + 1 - kQDG : false);
         const bool tile16 = (b & 3) == c;
         if (b < cx.NB && (!tile16 || t16 >= (b >> 2)) && __builtin_amdgcn_ballot_w64(late) == 0) {
+            q_stamp(cx, b, 1);
             if (tile16)
                 do_block(b, std::true_type{});
             else
                 do_block(b, std::false_type{});
+            q_stamp(cx, b, 3);
             ++b;
             spin = 0;
             continue;
@@ -372,6 +389,7 @@ __device__ __forceinline__ void q_h_wave(const GruQuadArgs &g, const QCtx &cx, c
         const int bq = b + 1;
         const bool real = bq < cx.NB && (bq >> 2) >= 1 && (j < 3 || (bq & 3) != c);
         u32x4 gr[4];
+        q_stamp(cx, b, 0);
         gather_load(real ? bq : 4 + m, gr);
 
         // ---- this block's inputs: pre-activations, every tile of h_{t-1} (own workgroup's, filed remote ones, tile 16)
@@ -384,6 +402,7 @@ __device__ __forceinline__ void q_h_wave(const GruQuadArgs &g, const QCtx &cx, c
                                                                        : INT_MIN;
             if (!q_wait(cx, need, 0x20000000u | (unsigned) (j << 24) | (unsigned) b)) return;
         }
+        q_stamp(cx, b, 1);
         const frag_t *ha = (const frag_t *) (cx.smem + kQOffHs + m * kQHsBytes);  // holds h_{t-1} now
         f32x4 acc[3], a16 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -394,6 +413,7 @@ __device__ __forceinline__ void q_h_wave(const GruQuadArgs &g, const QCtx &cx, c
         else
             q_h_mma<false>(acc, a16, ha, w, w16, lane);
         q_flag_write(cx.flags + (kFHM + j) * 4, b + 1);  // (behind this block's operand reads in the wave's DS queue)
+        q_stamp(cx, b, 2);
         if (with16) {
             *(f32x4 *) (cx.smem + kQOffGh16 + ((t & 1) * 3 + j) * 1024 + lane * 16) = a16;
             q_flag_write(cx.flags + (kFGH16 + j) * 4, t + 1);
@@ -408,13 +428,17 @@ __device__ __forceinline__ void q_h_wave(const GruQuadArgs &g, const QCtx &cx, c
         if (m == 1) hreg[1] = hnew;
         if (m == 2) hreg[2] = hnew;
         if (m == 3) hreg[3] = hnew;
+        q_stamp(cx, b, 3);
         // the image is rewritten in place: every h wave must be through with reading h_{t-1}
         {
             const int need = (cx.lane5 >= kFHM && cx.lane5 < kFHM + 4) ? b + 1 : INT_MIN;
             if (!q_wait(cx, need, 0x28000000u | (unsigned) (j << 24) | (unsigned) b)) return;
         }
+        q_stamp(cx, b, 4);
         q_publish(g, cx, t, m, u, hnew);
         q_flag_write(cx.flags + (kFHL + j) * 4, b + 1);
+        q_stamp(cx, b, 5);
+        int gspins = 0;
 
         // ---- file the remote tiles the next block reads (its image was last read by block bq - 4 <= b: see the wait above)
         if (real) {
@@ -433,7 +457,10 @@ __device__ __forceinline__ void q_h_wave(const GruQuadArgs &g, const QCtx &cx, c
                 __builtin_amdgcn_s_sleep(2);
                 asm volatile("" ::: "memory");
                 gather_load(bq, gr);
+                ++gspins;
             }
+            q_stamp(cx, b, 6);
+            q_note(cx, b, 7, (unsigned long long) gspins);
             char *img = cx.smem + kQOffHs + (bq & 3) * kQHsBytes + cx.lane_off;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -460,6 +487,7 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad_kernel(GruQuadArgs g
 
     QCtx cx;
     cx.smem = smem;
+    cx.dbg = (g.dbg && bid == g.dbg_block) ? g.dbg + (size_t) wave * 4 * g.T * 8 : nullptr;
     cx.flags = (unsigned) (uintptr_t) (smem + kQOffFlags);
     cx.flags_lane = cx.flags + (lane & 31) * 4;
     cx.err = g.err;

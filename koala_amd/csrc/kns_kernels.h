@@ -125,6 +125,8 @@ struct GruQuadArgs {
     int nb0, T, mtiles;
     unsigned serial;    // launch serial number (the high bits of every granule tag of this launch); never 0
     int quad0 = 0;      // first quad of this launch (set by launch_gru_quad: 64 quads per launch)
+    unsigned long long *dbg = nullptr;  // developer build: [8 waves][4 T blocks][8] s_memtime stamps of workgroup `dbg_block`
+    int dbg_block = 0;
 };
 // true when the shape is one the fused kernel takes (bf16, T >= 1, m-tiles in whole quads)
 bool gru_quad_supported(int precision, int mtiles, int nb0);
