@@ -149,21 +149,53 @@ __device__ __forceinline__ f32x4 q_gates(const f32x4 (&acc)[3], u32x2 pr, u32x2 
     return hnew;
 }
 
-// h_t of unit tile u, m-tile (local) m: own LDS image, granules for the other workgroups, hidden sequence in HBM
-__device__ __forceinline__ void q_publish(const GruQuadArgs &g, const QCtx &cx, int t, int m, int u, const f32x4 &hnew) {
-    unsigned w0, w1;
-    q_pack(hnew, cx.even, w0, w1);
-    char *img = cx.smem + kQOffHs + m * kQHsBytes + q_tile_off(u) + cx.lane_off;
-    *(unsigned *) img = w0;
-    *(unsigned *) (img + 16) = w1;
+// h_t of unit tile u, m-tile (local) m, as this lane's two packed operand words: to the other workgroups as granules and to the
+// hidden sequence in HBM.  The caller writes the words into the m-tile's LDS image (q_image_write) once nobody reads it.
+__device__ __forceinline__ void q_publish(const GruQuadArgs &g, const QCtx &cx, int t, int m, int u, unsigned w0, unsigned w1) {
     const int mt = cx.mt0 + m;
     const unsigned tag = cx.tag_base | (unsigned) (t + 1);
     const __amdgpu_buffer_rsrc_t gr =
         make_rsrc((char *) g.xchg + (((size_t) mt * 2 + (t & 1)) * 17 + u) * 1024, 1024);
     __builtin_amdgcn_raw_buffer_store_b128(u32x4{tag, w0, tag, w1}, gr, cx.lane * 16u, 0, 16 /* sc1: write through */);
-    char *hs = (char *) g.hseq + ((size_t) t * cx.mtiles + mt) * kQHsBytes + q_tile_off(u) + cx.lane_off;
-    *(unsigned *) hs = w0;
-    *(unsigned *) (hs + 16) = w1;
+    const __amdgpu_buffer_rsrc_t hr =
+        make_rsrc((char *) g.hseq + ((size_t) t * cx.mtiles + mt) * kQHsBytes + q_tile_off(u), 512);
+    __builtin_amdgcn_raw_buffer_store_b32(w0, hr, (unsigned) cx.lane_off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(w1, hr, (unsigned) cx.lane_off + 16u, 0, 0);
+}
+__device__ __forceinline__ void q_image_write(const QCtx &cx, int m, int u, unsigned w0, unsigned w1) {
+    char *img = cx.smem + kQOffHs + m * kQHsBytes + q_tile_off(u) + cx.lane_off;
+    *(unsigned *) img = w0;
+    *(unsigned *) (img + 16) = w1;
+}
+
+// ---- remote tiles of h: requested from the exchange buffer (sc1: from L2, never this CU's L1), checked, filed into an image
+struct QGather {
+    u32x4 gr[4];
+};
+// the h that block bq READS (step (bq >> 2) - 1 of m-tile bq & 3), tiles tile0 + i * tstep
+__device__ __forceinline__ void q_gather_load(const GruQuadArgs &g, const QCtx &cx, int bq, int tile0, int tstep, QGather &q) {
+    const int ts = (bq >> 2) - 1, mq = bq & 3;
+    const size_t slot = ((size_t) (cx.mt0 + mq) * 2 + (ts & 1)) * 17;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __amdgpu_buffer_rsrc_t r = make_rsrc((const char *) g.xchg + (slot + tile0 + i * tstep) * 1024, 1024);
+        q.gr[i] = __builtin_amdgcn_raw_buffer_load_b128(r, cx.lane * 16u, 0, 16);
+    }
+}
+__device__ __forceinline__ bool q_gather_valid(const QCtx &cx, int bq, const QGather &q) {
+    const unsigned tag = cx.tag_base | (unsigned) (bq >> 2);  // step (bq >> 2) - 1, + 1
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ok = ok && q.gr[i][0] == tag && q.gr[i][2] == tag;
+    return __builtin_amdgcn_ballot_w64(!ok) == 0;
+}
+__device__ __forceinline__ void q_gather_file(const QCtx &cx, int bq, int tile0, int tstep, const QGather &q) {
+    char *img = cx.smem + kQOffHs + (bq & 3) * kQHsBytes + cx.lane_off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *(unsigned *) (img + q_tile_off(tile0 + i * tstep)) = q.gr[i][1];
+        *(unsigned *) (img + q_tile_off(tile0 + i * tstep) + 16) = q.gr[i][3];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ x waves
@@ -261,14 +293,44 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
     };
 
     if (j < 3) {
-        for (int b = 0; b < cx.NB; ++b) {
-            // the x operand of this block is staged and the ring slot is free
-            const int need = cx.lane5 < 4 ? b + 1 : cx.lane5 == kFGC + j ? b + 1 - kQDG : INT_MIN;
-            q_stamp(cx, b, 0);
+        // Waves 0..2 also FILE the remote tiles of h: wave j the four tiles of workgroup (c + 1 + j) & 3.  In its block b it
+        // requests what h-block b - 2 reads (produced remotely in h-block b - 6, about two blocks in the past since the x waves
+        // run four blocks ahead of the h waves), checks the tags after its own MFMAs and writes the words into the LDS image.
+        const int rq = (c + 1 + j) & 3;
+        for (int b = 0; b < cx.NB + 2; ++b) {
+            const int gq = b - 2;
+            const bool real = gq >= 4 && gq < cx.NB;
+            // the x operand of this block is staged, the ring slot is free; the image of h-block gq was last read by h-block gq - 4
+            const int need = b < cx.NB ? (cx.lane5 < 4 ? b + 1
+                                          : cx.lane5 == kFGC + j ? b + 1 - kQDG
+                                          : (cx.lane5 >= kFHM && cx.lane5 < kFHM + 4) ? gq - 3
+                                                                                       : INT_MIN)
+                                       : ((cx.lane5 >= kFHM && cx.lane5 < kFHM + 4) ? gq - 3 : INT_MIN);
+            q_stamp(cx, b < cx.NB ? b : cx.NB - 1, 0);
             if (!q_wait(cx, need, 0x10000000u | (unsigned) (j << 24) | (unsigned) b)) return;
-            q_stamp(cx, b, 1);
-            do_block(b, std::false_type{});
-            q_stamp(cx, b, 3);
+            q_stamp(cx, b < cx.NB ? b : cx.NB - 1, 1);
+            QGather q;
+            q_gather_load(g, cx, real ? gq : 4 + (b & 3), 4 * rq, 1, q);
+            if (b < cx.NB) do_block(b, std::false_type{});
+            q_stamp(cx, b < cx.NB ? b : cx.NB - 1, 3);
+            if (real) {
+                int spins = 0;
+                while (!q_gather_valid(cx, gq, q)) {
+                    const int v = q_flags_read(cx.flags_lane);
+                    if (__builtin_amdgcn_readlane(v, kFAbort) != 0) return;
+                    if (++spins > kQGatherLimit) {
+                        q_abort(cx, 0x30000000u | (unsigned) (j << 24) | (unsigned) gq);
+                        return;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                    asm volatile("" ::: "memory");
+                    q_gather_load(g, cx, gq, 4 * rq, 1, q);
+                }
+                q_gather_file(cx, gq, 4 * rq, 1, q);
+                q_flag_write(cx.flags + (kFHG + j) * 4, gq + 1);
+                q_note(cx, b < cx.NB ? b : cx.NB - 1, 7, (unsigned long long) spins);
+                q_stamp(cx, b < cx.NB ? b : cx.NB - 1, 4);
+            }
         }
         return;
     }
@@ -280,13 +342,44 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
                 bh16n = g.bhh[(16 * 3 + 2) * 16 + cx.colq];
     f32x4 h16 = ((const f32x4 *) g.hstate_in)[((size_t) (cx.mt0 + c) * kUnitTiles + 16) * 64 + lane];
     int b = 0, t16 = 0, spin = 0;
-    while (b < cx.NB || t16 < cx.T) {
+    // unit tile 16 of the OTHER m-tiles comes from the workgroups that serve it: requested when h-block g16 - 4 (which
+    // produced it remotely) is about two blocks in the past, checked an action later
+    int g16 = 4;          // next h-block whose tile 16 is to be filed
+    bool g16_issued = false;
+    QGather q16;
+    while (b < cx.NB || t16 < cx.T || g16 < cx.NB) {
         const int v = q_flags_read(cx.flags_lane);
         if (__builtin_amdgcn_readlane(v, kFAbort) != 0) return;
+        if (g16 < cx.NB) {
+            if ((g16 & 3) == c) {  // served by this workgroup: nothing to fetch (kFH16 covers it)
+                q_flag_write(cx.flags + (kFHG + 3) * 4, g16 + 1);
+                ++g16;
+                continue;
+            }
+            if (g16_issued) {
+                if (q_gather_valid(cx, g16, q16)) {
+                    q_gather_file(cx, g16, 16, 0, q16);
+                    q_flag_write(cx.flags + (kFHG + 3) * 4, g16 + 1);
+                    ++g16;
+                    g16_issued = false;
+                    spin = 0;
+                    continue;
+                }
+                g16_issued = false;  // late: ask again below
+            }
+            // readers of the image (h-block g16 - 4) are through, and this wave is far enough ahead for the data to exist
+            const bool busy = (cx.lane5 >= kFHM && cx.lane5 < kFHM + 4) ? v < g16 - 3 : false;
+            if ((g16 <= b - 2 || b >= cx.NB) && __builtin_amdgcn_ballot_w64(busy) == 0) {
+                asm volatile("" ::: "memory");
+                q_gather_load(g, cx, g16, 16, 0, q16);
+                g16_issued = true;
+            }
+        }
         // gate math of step t16: this wave has been through block (t16, c) (gi16 holds that step), the three recurrent
-        // accumulators are in LDS, and h wave 3 too has finished reading the image the result goes into
+        // accumulators are in LDS, and every h wave has finished reading the image the result goes into
         const int b16 = 4 * t16 + c;
-        const bool late16 = (cx.lane5 >= kFGH16 && cx.lane5 < kFGH16 + 3) ? v < t16 + 1 : (cx.lane5 == kFHM + 3 ? v < b16 + 1 : false);
+        const bool late16 = (cx.lane5 >= kFGH16 && cx.lane5 < kFGH16 + 3) ? v < t16 + 1
+                            : ((cx.lane5 >= kFHM && cx.lane5 < kFHM + 4) ? v < b16 + 1 : false);
         if (t16 < cx.T && b > b16 && __builtin_amdgcn_ballot_w64(late16) == 0) {
             const int t = t16;
             const char *gh = cx.smem + kQOffGh16 + (t & 1) * 3 * 1024 + lane * 16;
@@ -297,8 +390,11 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
             q_flag_write(cx.flags + kFG16C * 4, t + 1);  // (behind the reads in this wave's DS queue)
             q_stamp(cx, b16, 4);
             h16 = q_gates(acc, gi16[0], gi16[1], gi16[2], bh16r, bh16z, bh16n, h16);
-            q_publish(g, cx, t, c, 16, h16);
+            unsigned w0, w1;
+            q_pack(h16, cx.even, w0, w1);
+            q_image_write(cx, c, 16, w0, w1);
             q_flag_write(cx.flags + kFH16 * 4, t + 1);
+            q_publish(g, cx, t, c, 16, w0, w1);
             q_stamp(cx, b16, 5);
             ++t16;
             spin = 0;
@@ -369,38 +465,26 @@ __device__ __forceinline__ void q_h_wave(const GruQuadArgs &g, const QCtx &cx, c
 #pragma unroll
     for (int m = 0; m < 4; ++m) hreg[m] = ((const f32x4 *) g.hstate_in)[((size_t) (cx.mt0 + m) * kUnitTiles + u) * 64 + lane];
 
-    // Remote tiles this wave files into the LDS images: waves 0..2 the four tiles of workgroup (c + 1 + j) & 3, wave 3 unit
-    // tile 16 from the workgroup that serves it for the m-tile (none when that is this workgroup).
-    const int rq = (c + 1 + j) & 3;
-    auto gather_tile = [&](int i) { return j < 3 ? 4 * rq + i : 16; };
-    auto gather_load = [&](int bq, u32x4 (&gr)[4]) {  // the h that block bq READS: step (bq >> 2) - 1 of m-tile bq & 3
-        const int ts = (bq >> 2) - 1, mq = bq & 3;
-        const size_t slot = ((size_t) (cx.mt0 + mq) * 2 + (ts & 1)) * 17;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const __amdgpu_buffer_rsrc_t r = make_rsrc((const char *) g.xchg + (slot + gather_tile(i)) * 1024, 1024);
-            gr[i] = __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16u, 0, 16 /* sc1: from L2, never this CU's L1 */);
-        }
-    };
-
+    unsigned w0p = 0, w1p = 0;  // block b - 1's tile, not yet in its image (readers may still have been at it)
     for (int b = 0; b < cx.NB; ++b) {
         const int t = b >> 2, m = b & 3;
-        // ---- request what the next block reads (redirected to something harmless where there is nothing to get)
-        const int bq = b + 1;
-        const bool real = bq < cx.NB && (bq >> 2) >= 1 && (j < 3 || (bq & 3) != c);
-        u32x4 gr[4];
         q_stamp(cx, b, 0);
-        gather_load(real ? bq : 4 + m, gr);
-
-        // ---- this block's inputs: pre-activations, every tile of h_{t-1} (own workgroup's, filed remote ones, tile 16)
+        // ---- ONE wait per block: this block's pre-activations; every tile of h_{t-1} in the image (this workgroup's tiles of
+        // h-block b - 4, the remote ones filed by the x waves, tile 16); every h wave through with READING h-block b - 1's
+        // image, so that this wave's tile of that block can go in
         {
             const int need = cx.lane5 == kFGI + j ? b + 1
                              : (cx.lane5 >= kFHL && cx.lane5 < kFHL + 4) ? b - 3
                              : (cx.lane5 >= kFHG && cx.lane5 < kFHG + 4) ? b + 1
+                             : (cx.lane5 >= kFHM && cx.lane5 < kFHM + 4) ? b
                              : (cx.lane5 == kFH16 && m == c) ? t
                              : (cx.lane5 == kFG16C && m == c && j < 3) ? t - 1
                                                                        : INT_MIN;
             if (!q_wait(cx, need, 0x20000000u | (unsigned) (j << 24) | (unsigned) b)) return;
+        }
+        if (b > 0) {
+            q_image_write(cx, (b - 1) & 3, u, w0p, w1p);
+            q_flag_write(cx.flags + (kFHL + j) * 4, b);
         }
         q_stamp(cx, b, 1);
         const frag_t *ha = (const frag_t *) (cx.smem + kQOffHs + m * kQHsBytes);  // holds h_{t-1} now
@@ -429,46 +513,9 @@ __device__ __forceinline__ void q_h_wave(const GruQuadArgs &g, const QCtx &cx, c
         if (m == 2) hreg[2] = hnew;
         if (m == 3) hreg[3] = hnew;
         q_stamp(cx, b, 3);
-        // the image is rewritten in place: every h wave must be through with reading h_{t-1}
-        {
-            const int need = (cx.lane5 >= kFHM && cx.lane5 < kFHM + 4) ? b + 1 : INT_MIN;
-            if (!q_wait(cx, need, 0x28000000u | (unsigned) (j << 24) | (unsigned) b)) return;
-        }
-        q_stamp(cx, b, 4);
-        q_publish(g, cx, t, m, u, hnew);
-        q_flag_write(cx.flags + (kFHL + j) * 4, b + 1);
+        q_pack(hnew, cx.even, w0p, w1p);
+        q_publish(g, cx, t, m, u, w0p, w1p);
         q_stamp(cx, b, 5);
-        int gspins = 0;
-
-        // ---- file the remote tiles the next block reads (its image was last read by block bq - 4 <= b: see the wait above)
-        if (real) {
-            const unsigned tag = cx.tag_base | (unsigned) (bq >> 2);  // step (bq >> 2) - 1, + 1
-            for (int spin = 0;; ++spin) {
-                bool ok = true;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) ok = ok && gr[i][0] == tag && gr[i][2] == tag;
-                if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
-                const int v = q_flags_read(cx.flags_lane);
-                if (__builtin_amdgcn_readlane(v, kFAbort) != 0) return;
-                if (spin > kQGatherLimit) {
-                    q_abort(cx, 0x30000000u | (unsigned) (j << 24) | (unsigned) bq);
-                    return;
-                }
-                __builtin_amdgcn_s_sleep(2);
-                asm volatile("" ::: "memory");
-                gather_load(bq, gr);
-                ++gspins;
-            }
-            q_stamp(cx, b, 6);
-            q_note(cx, b, 7, (unsigned long long) gspins);
-            char *img = cx.smem + kQOffHs + (bq & 3) * kQHsBytes + cx.lane_off;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *(unsigned *) (img + q_tile_off(gather_tile(i))) = gr[i][1];
-                *(unsigned *) (img + q_tile_off(gather_tile(i)) + 16) = gr[i][3];
-            }
-        }
-        if (bq >= 4) q_flag_write(cx.flags + (kFHG + j) * 4, bq + 1);
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m) ((f32x4 *) g.hstate_out)[((size_t) (cx.mt0 + m) * kUnitTiles + u) * 64 + lane] = hreg[m];

@@ -38,24 +38,22 @@ def main():
     print('workgroup %d, T = %d: last stamp at %.0f ticks; steady-state blocks %d..%d' % (wg, T, total, lo, hi))
     step = np.diff(st[4, lo:hi:4, 0]).mean()
     print('ticks per step (h wave 0, block start to block start 4 blocks later): %.0f' % step)
-    names = ['start->inputs ready', 'MFMA', 'gi+gates', 'wait readers', 'publish', 'gather poll', 'file']
     for w in range(4, 8):
         s = st[w, lo:hi]
-        d = [s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2], s[:, 4] - s[:, 3], s[:, 5] - s[:, 4]]
-        real = s[:, 6] > 0
-        d.append(np.where(real, s[:, 6] - s[:, 5], 0))
         nxt = np.concatenate([s[1:, 0], s[-1:, 0]])
-        d.append(nxt - np.where(real, s[:, 6], s[:, 5]))
-        print('h wave %d: ' % (w - 4) + '  '.join('%s %.0f' % (nm, v.mean()) for nm, v in zip(names, d)) +
-              '  | gather re-polls per block %.2f' % s[:, 7].mean())
+        d = [s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2], s[:, 5] - s[:, 3], nxt - s[:, 5]]
+        print('h wave %d: wait(+deferred tile write) %.0f  MFMA %.0f  gi+gates %.0f  pack+publish %.0f  loop %.0f' % (
+            (w - 4,) + tuple(v.mean() for v in d)))
         for m in range(4):
-            print('     m=%d: wait %.0f  mfma %.0f  gates %.0f  readers %.0f  publish %.0f  poll %.0f' % (
-                m, d[0][m::4].mean(), d[1][m::4].mean(), d[2][m::4].mean(), d[3][m::4].mean(), d[4][m::4].mean(), d[5][m::4].mean()))
+            print('     m=%d: wait %.0f  mfma %.0f  gates %.0f  publish %.0f' % (
+                m, d[0][m::4].mean(), d[1][m::4].mean(), d[2][m::4].mean(), d[3][m::4].mean()))
     for w in range(0, 4):
         s = st[w, lo:hi]
         if w < 3:
-            print('x wave %d: wait %.0f  mfma %.0f  epilogue+stage %.0f | block-to-block %.0f' % (
-                w, (s[:, 1] - s[:, 0]).mean(), (s[:, 2] - s[:, 1]).mean(), (s[:, 3] - s[:, 2]).mean(), np.diff(s[:, 1]).mean()))
+            filed = s[:, 4] > 0
+            print('x wave %d: wait %.0f  gather issue + mfma %.0f  epilogue+stage %.0f  check+file %.0f | block-to-block %.0f | '
+                  're-polls per block %.2f' % (w, (s[:, 1] - s[:, 0]).mean(), (s[:, 2] - s[:, 1]).mean(), (s[:, 3] - s[:, 2]).mean(),
+                                              (s[:, 4] - s[:, 3])[filed].mean(), np.diff(s[:, 1]).mean(), s[:, 7].mean()))
         else:
             print('x wave 3: mfma %.0f  epilogue+stage(+tile 16 projection) %.0f | block-to-block %.0f | tile-16 gates %.0f' % (
                 (s[:, 2] - s[:, 1]).mean(), (s[:, 3] - s[:, 2]).mean(), np.diff(s[:, 1]).mean(),
