@@ -294,11 +294,12 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
 
     if (j < 3) {
         // Waves 0..2 also FILE the remote tiles of h: wave j the four tiles of workgroup (c + 1 + j) & 3.  In its block b it
-        // requests what h-block b - 2 reads (produced remotely in h-block b - 6, about two blocks in the past since the x waves
-        // run four blocks ahead of the h waves), checks the tags after its own MFMAs and writes the words into the LDS image.
+        // requests what h-block b - 1 reads (produced remotely in h-block b - 5, one or two blocks in the past since the x waves
+        // run three to four blocks ahead of the h waves), checks the tags after its own MFMAs and writes the words into the
+        // LDS image.
         const int rq = (c + 1 + j) & 3;
-        for (int b = 0; b < cx.NB + 2; ++b) {
-            const int gq = b - 2;
+        for (int b = 0; b < cx.NB + 1; ++b) {
+            const int gq = b - 1;
             const bool real = gq >= 4 && gq < cx.NB;
             // the x operand of this block is staged, the ring slot is free; the image of h-block gq was last read by h-block gq - 4
             const int need = b < cx.NB ? (cx.lane5 < 4 ? b + 1
@@ -342,8 +343,8 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
                 bh16n = g.bhh[(16 * 3 + 2) * 16 + cx.colq];
     f32x4 h16 = ((const f32x4 *) g.hstate_in)[((size_t) (cx.mt0 + c) * kUnitTiles + 16) * 64 + lane];
     int b = 0, t16 = 0, spin = 0;
-    // unit tile 16 of the OTHER m-tiles comes from the workgroups that serve it: requested when h-block g16 - 4 (which
-    // produced it remotely) is about two blocks in the past, checked an action later
+    // unit tile 16 of the OTHER m-tiles comes from the workgroups that serve it: requested once this workgroup's h waves are
+    // through h-block g16 - 4 (whose remote twin produces it), checked an action later
     int g16 = 4;          // next h-block whose tile 16 is to be filed
     bool g16_issued = false;
     QGather q16;
@@ -367,9 +368,9 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
                 }
                 g16_issued = false;  // late: ask again below
             }
-            // readers of the image (h-block g16 - 4) are through, and this wave is far enough ahead for the data to exist
+            // the readers of the image (h-block g16 - 4, whose remote twin produced the tile) are through
             const bool busy = (cx.lane5 >= kFHM && cx.lane5 < kFHM + 4) ? v < g16 - 3 : false;
-            if ((g16 <= b - 2 || b >= cx.NB) && __builtin_amdgcn_ballot_w64(busy) == 0) {
+            if (__builtin_amdgcn_ballot_w64(busy) == 0) {
                 asm volatile("" ::: "memory");
                 q_gather_load(g, cx, g16, 16, 0, q16);
                 g16_issued = true;
