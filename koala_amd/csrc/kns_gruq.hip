@@ -100,11 +100,13 @@ __device__ __forceinline__ void q_abort(const QCtx &cx, unsigned code) {
 }
 
 // waits until flag[i] >= need(i) for every word (need is this lane's requirement for word lane & 31; INT_MIN = none)
-__device__ __forceinline__ bool q_wait(const QCtx &cx, int need, unsigned code) {
+__device__ __forceinline__ bool q_wait(const QCtx &cx, int need, unsigned code, int dbg_block = -1) {
     for (int spin = 0;; ++spin) {
         const int v = q_flags_read(cx.flags_lane);
         if (__builtin_amdgcn_readlane(v, kFAbort) != 0) return false;
-        if (__builtin_amdgcn_ballot_w64(v < need) == 0) return true;
+        const unsigned long long lag = __builtin_amdgcn_ballot_w64(v < need);
+        if (spin == 0 && dbg_block >= 0) q_note(cx, dbg_block, 6, lag & 0xffffffffull);  // which counters were behind at first look
+        if (lag == 0) return true;
         if (spin > kQSpinLimit) {
             q_abort(cx, code);
             return false;
@@ -308,7 +310,7 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
                                                                                        : INT_MIN)
                                        : ((cx.lane5 >= kFHM && cx.lane5 < kFHM + 4) ? gq - 3 : INT_MIN);
             q_stamp(cx, b < cx.NB ? b : cx.NB - 1, 0);
-            if (!q_wait(cx, need, 0x10000000u | (unsigned) (j << 24) | (unsigned) b)) return;
+            if (!q_wait(cx, need, 0x10000000u | (unsigned) (j << 24) | (unsigned) b, b < cx.NB ? b : -1)) return;
             q_stamp(cx, b < cx.NB ? b : cx.NB - 1, 1);
             QGather q;
             q_gather_load(g, cx, real ? gq : 4 + (b & 3), 4 * rq, 1, q);
@@ -481,7 +483,7 @@ __device__ __forceinline__ void q_h_wave(const GruQuadArgs &g, const QCtx &cx, c
                              : (cx.lane5 == kFH16 && m == c) ? t
                              : (cx.lane5 == kFG16C && m == c && j < 3) ? t - 1
                                                                        : INT_MIN;
-            if (!q_wait(cx, need, 0x20000000u | (unsigned) (j << 24) | (unsigned) b)) return;
+            if (!q_wait(cx, need, 0x20000000u | (unsigned) (j << 24) | (unsigned) b, b)) return;
         }
         if (b > 0) {
             q_image_write(cx, (b - 1) & 3, u, w0p, w1p);

@@ -58,6 +58,17 @@ def main():
             print('x wave 3: mfma %.0f  epilogue+stage(+tile 16 projection) %.0f | block-to-block %.0f | tile-16 gates %.0f' % (
                 (s[:, 2] - s[:, 1]).mean(), (s[:, 3] - s[:, 2]).mean(), np.diff(s[:, 1]).mean(),
                 np.mean([v for v in (s[:, 5] - s[:, 4]) if v > 0])))
+    groups = [('XW', 0, 4), ('GI', 4, 8), ('GC', 8, 12), ('HL', 12, 16), ('HG', 16, 20), ('HM', 20, 24), ('GH16', 24, 27),
+              ('G16C', 27, 28), ('H16', 28, 29)]
+    for w in (0, 4, 7):
+        masks = st[w, lo:hi, 6].astype(np.int64)
+        txt = []
+        for nm, a, b_ in groups:
+            for i in range(a, b_):
+                frac = float(((masks >> i) & 1).mean())
+                if frac > 0.02:
+                    txt.append('%s[%d] %.0f%%' % (nm, i - a, 100 * frac))
+        print('wave %d: counters behind at the first look of a block\'s wait: %s' % (w, ', '.join(txt) or 'none'))
     # lead of the x waves over the h waves: block index of x wave 0 when h wave 0 starts block b
     hx = st[4, lo:hi, 1]
     xs = st[0, :, 3]
