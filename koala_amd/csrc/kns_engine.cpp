@@ -1027,8 +1027,13 @@ int64_t Engine::debug_read(int what, float *out, int64_t capacity, std::string *
         const unsigned long long *st = (const unsigned long long *) h.data();
         unsigned long long t0 = ~0ull;
         for (int64_t i = 0; i < n; ++i)
-            if (i % 8 != 7 && st[i] && st[i] < t0) t0 = st[i];
-        for (int64_t i = 0; i < n; ++i) out[i] = i % 8 == 7 ? (float) st[i] : (st[i] ? (float) (st[i] - t0) : -1.0f);
+            if (i % 8 < 6 && st[i] && st[i] < t0) t0 = st[i];
+        // slots 0..5: ticks since the first stamp; slot 6: a 32-bit mask as two 16-bit halves is too wide for a float -- split
+        // below; slot 7: a small count
+        for (int64_t i = 0; i < n; ++i)
+            out[i] = i % 8 == 7 ? (float) (st[i] & 0xffff) + 65536.0f * (float) (st[i - 1] >> 16 & 0xffff)  // count + mask's high half
+                     : i % 8 == 6 ? (float) (st[i] & 0xffff)
+                                  : (st[i] ? (float) (st[i] - t0) : -1.0f);
     } else {
         *err = "unknown debug tap";
         return -1;

@@ -53,7 +53,7 @@ def main():
             filed = s[:, 4] > 0
             print('x wave %d: wait %.0f  gather issue + mfma %.0f  epilogue+stage %.0f  check+file %.0f | block-to-block %.0f | '
                   're-polls per block %.2f' % (w, (s[:, 1] - s[:, 0]).mean(), (s[:, 2] - s[:, 1]).mean(), (s[:, 3] - s[:, 2]).mean(),
-                                              (s[:, 4] - s[:, 3])[filed].mean(), np.diff(s[:, 1]).mean(), s[:, 7].mean()))
+                                              (s[:, 4] - s[:, 3])[filed].mean(), np.diff(s[:, 1]).mean(), (s[:, 7].astype(np.int64) & 0xffff).mean()))
         else:
             print('x wave 3: mfma %.0f  epilogue+stage(+tile 16 projection) %.0f | block-to-block %.0f | tile-16 gates %.0f' % (
                 (s[:, 2] - s[:, 1]).mean(), (s[:, 3] - s[:, 2]).mean(), np.diff(s[:, 1]).mean(),
@@ -61,7 +61,7 @@ def main():
     groups = [('XW', 0, 4), ('GI', 4, 8), ('GC', 8, 12), ('HL', 12, 16), ('HG', 16, 20), ('HM', 20, 24), ('GH16', 24, 27),
               ('G16C', 27, 28), ('H16', 28, 29)]
     for w in (0, 4, 7):
-        masks = st[w, lo:hi, 6].astype(np.int64)
+        masks = st[w, lo:hi, 6].astype(np.int64) + ((st[w, lo:hi, 7].astype(np.int64) >> 16) << 16)
         txt = []
         for nm, a, b_ in groups:
             for i in range(a, b_):
