@@ -173,6 +173,7 @@ __device__ __forceinline__ void q_image_write(const QCtx &cx, int m, int u, unsi
 // ---- remote tiles of h: requested from the exchange buffer (sc1: from L2, never this CU's L1), checked, filed into an image
 struct QGather {
     u32x4 gr[4];
+    u32x4 g16;  // unit tile 16 (x wave 0 only)
 };
 // the h that block bq READS (step (bq >> 2) - 1 of m-tile bq & 3), tiles tile0 + i * tstep
 __device__ __forceinline__ void q_gather_load(const GruQuadArgs &g, const QCtx &cx, int bq, int tile0, int tstep, QGather &q) {
@@ -314,11 +315,24 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
             q_stamp(cx, b < cx.NB ? b : cx.NB - 1, 1);
             QGather q;
             q_gather_load(g, cx, real ? gq : 4 + (b & 3), 4 * rq, 1, q);
+            // wave 0 also fetches unit tile 16 of the m-tile from the workgroup that serves it (nothing to fetch when that is
+            // this one: kFH16 covers it)
+            const bool real16 = real && j == 0 && (gq & 3) != c;
+            {
+                const int bq = real ? gq : 4 + (b & 3);
+                const size_t slot = ((size_t) (cx.mt0 + (bq & 3)) * 2 + (((bq >> 2) - 1) & 1)) * 17 + 16;
+                q.g16 = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc((const char *) g.xchg + slot * 1024, 1024), lane * 16u, 0, 16);
+            }
             if (b < cx.NB) do_block(b, std::false_type{});
             q_stamp(cx, b < cx.NB ? b : cx.NB - 1, 3);
             if (real) {
                 int spins = 0;
-                while (!q_gather_valid(cx, gq, q)) {
+                auto valid = [&]() {
+                    if (!q_gather_valid(cx, gq, q)) return false;
+                    const unsigned tag = cx.tag_base | (unsigned) (gq >> 2);
+                    return !real16 || __builtin_amdgcn_ballot_w64(q.g16[0] != tag || q.g16[2] != tag) == 0;
+                };
+                while (!valid()) {
                     const int v = q_flags_read(cx.flags_lane);
                     if (__builtin_amdgcn_readlane(v, kFAbort) != 0) return;
                     if (++spins > kQGatherLimit) {
@@ -328,9 +342,17 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
                     __builtin_amdgcn_s_sleep(2);
                     asm volatile("" ::: "memory");
                     q_gather_load(g, cx, gq, 4 * rq, 1, q);
+                    const size_t slot = ((size_t) (cx.mt0 + (gq & 3)) * 2 + (((gq >> 2) - 1) & 1)) * 17 + 16;
+                    q.g16 = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc((const char *) g.xchg + slot * 1024, 1024), lane * 16u, 0, 16);
                 }
                 q_gather_file(cx, gq, 4 * rq, 1, q);
+                if (real16) {
+                    char *img = cx.smem + kQOffHs + (gq & 3) * kQHsBytes + cx.lane_off + q_tile_off(16);
+                    *(unsigned *) img = q.g16[1];
+                    *(unsigned *) (img + 16) = q.g16[3];
+                }
                 q_flag_write(cx.flags + (kFHG + j) * 4, gq + 1);
+                if (j == 0) q_flag_write(cx.flags + (kFHG + 3) * 4, gq + 1);
                 q_note(cx, b < cx.NB ? b : cx.NB - 1, 7, (unsigned long long) spins);
                 q_stamp(cx, b < cx.NB ? b : cx.NB - 1, 4);
             }
@@ -345,39 +367,9 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
                 bh16n = g.bhh[(16 * 3 + 2) * 16 + cx.colq];
     f32x4 h16 = ((const f32x4 *) g.hstate_in)[((size_t) (cx.mt0 + c) * kUnitTiles + 16) * 64 + lane];
     int b = 0, t16 = 0, spin = 0;
-    // unit tile 16 of the OTHER m-tiles comes from the workgroups that serve it: requested once this workgroup's h waves are
-    // through h-block g16 - 4 (whose remote twin produces it), checked an action later
-    int g16 = 4;          // next h-block whose tile 16 is to be filed
-    bool g16_issued = false;
-    QGather q16;
-    while (b < cx.NB || t16 < cx.T || g16 < cx.NB) {
+    while (b < cx.NB || t16 < cx.T) {
         const int v = q_flags_read(cx.flags_lane);
         if (__builtin_amdgcn_readlane(v, kFAbort) != 0) return;
-        if (g16 < cx.NB) {
-            if ((g16 & 3) == c) {  // served by this workgroup: nothing to fetch (kFH16 covers it)
-                q_flag_write(cx.flags + (kFHG + 3) * 4, g16 + 1);
-                ++g16;
-                continue;
-            }
-            if (g16_issued) {
-                if (q_gather_valid(cx, g16, q16)) {
-                    q_gather_file(cx, g16, 16, 0, q16);
-                    q_flag_write(cx.flags + (kFHG + 3) * 4, g16 + 1);
-                    ++g16;
-                    g16_issued = false;
-                    spin = 0;
-                    continue;
-                }
-                g16_issued = false;  // late: ask again below
-            }
-            // the readers of the image (h-block g16 - 4, whose remote twin produced the tile) are through
-            const bool busy = (cx.lane5 >= kFHM && cx.lane5 < kFHM + 4) ? v < g16 - 3 : false;
-            if (__builtin_amdgcn_ballot_w64(busy) == 0) {
-                asm volatile("" ::: "memory");
-                q_gather_load(g, cx, g16, 16, 0, q16);
-                g16_issued = true;
-            }
-        }
         // gate math of step t16: this wave has been through block (t16, c) (gi16 holds that step), the three recurrent
         // accumulators are in LDS, and every h wave has finished reading the image the result goes into
         const int b16 = 4 * t16 + c;
