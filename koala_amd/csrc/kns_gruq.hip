@@ -35,6 +35,10 @@ namespace kns {
 
 constexpr int kQWaves = 8;
 constexpr int kQDG = 4;                               // depth of the pre-activation rings, in blocks
+#ifndef KQ_QA
+#define KQ_QA 4
+#endif
+constexpr int kQA = KQ_QA;                            // operand fragments in flight (LDS -> register) in the MFMA loops
 constexpr int kQHsBytes = 9 * 1024;                   // one hidden-state operand image: 9 k-blocks in A-fragment order
 constexpr int kQOffHs = 0;                            // [4 m-tiles]: h_{t-1} while a block reads it, then h_t tile by tile
 constexpr int kQOffXs = 4 * kQHsBytes;                // [2][NBX] KiB (sized for NBX = 11)
@@ -206,16 +210,16 @@ __device__ __forceinline__ void q_gather_file(const QCtx &cx, int bq, int tile0,
 // 3 x NBX MFMAs of one block against the wave's register-resident W_ih tile
 template <int NBX>
 __device__ __forceinline__ void q_x_mma(f32x4 (&acc)[3], const bf16x8 *xa, const bf16x8 (&w)[3][NBX], int lane) {
-    bf16x8 qa[2];
-    qa[0] = xa[lane];
-    qa[1] = xa[64 + lane];
+    bf16x8 qa[kQA];
+#pragma unroll
+    for (int p = 0; p < kQA; ++p) qa[p] = xa[p * 64 + lane];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int blk = 0; blk < NBX; ++blk) {
-        const bf16x8 a = qa[blk & 1];
+        const bf16x8 a = qa[blk % kQA];
 #pragma unroll
         for (int gt = 0; gt < 3; ++gt) acc[gt] = PBF16::mma(a, w[gt][blk], acc[gt]);
-        if (blk + 2 < NBX) qa[blk & 1] = xa[(blk + 2) * 64 + lane];
+        if (blk + kQA < NBX) qa[blk % kQA] = xa[(blk + kQA) * 64 + lane];
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -425,23 +429,22 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
 template <bool kW16>
 __device__ __forceinline__ void q_h_mma(f32x4 (&acc)[3], f32x4 &a16, const bf16x8 *ha, const bf16x8 (&w)[27], const bf16x8 *w16,
                                         int lane) {
-    bf16x8 qa[2], qw[2];
-    qa[0] = ha[lane];
-    qa[1] = ha[64 + lane];
-    if (kW16) {
-        qw[0] = w16[lane];
-        qw[1] = w16[64 + lane];
+    bf16x8 qa[kQA], qw[kQA];
+#pragma unroll
+    for (int p = 0; p < kQA; ++p) {
+        qa[p] = ha[p * 64 + lane];
+        if (kW16) qw[p] = w16[p * 64 + lane];
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int blk = 0; blk < 9; ++blk) {
-        const bf16x8 a = qa[blk & 1];
+        const bf16x8 a = qa[blk % kQA];
 #pragma unroll
         for (int gt = 0; gt < 3; ++gt) acc[gt] = PBF16::mma(a, w[blk * 3 + gt], acc[gt]);
-        if (kW16) a16 = PBF16::mma(a, qw[blk & 1], a16);
-        if (blk + 2 < 9) {
-            qa[blk & 1] = ha[(blk + 2) * 64 + lane];
-            if (kW16) qw[blk & 1] = w16[(blk + 2) * 64 + lane];
+        if (kW16) a16 = PBF16::mma(a, qw[blk % kQA], a16);
+        if (blk + kQA < 9) {
+            qa[blk % kQA] = ha[(blk + kQA) * 64 + lane];
+            if (kW16) qw[blk % kQA] = w16[(blk + kQA) * 64 + lane];
         }
         __builtin_amdgcn_sched_barrier(0);
     }
