@@ -250,6 +250,10 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
         bi[gt] = g.bih[(u * 3 + gt) * 16 + cx.colq];
     }
     const frag_t *w16 = (const frag_t *) (cx.smem + kQOffW16x);
+    // The resident weights have arrived before the loop is entered -- said explicitly: hipcc's wait-count pass otherwise merges
+    // "still in flight" from the loop's entry edge into the loop header and makes every block's MFMAs wait for the vector-memory
+    // operations of the block before (vmcnt counts them all).
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 
     // this wave's share of a block's x operand: k-blocks j, j + 4, j + 8 (clamped: an extra copy of the last one is harmless)
     const int p0 = j, p1 = j + 4, p2 = j + 8 < NBX ? j + 8 : NBX - 1;
@@ -360,6 +364,9 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
                 q_note(cx, b < cx.NB ? b : cx.NB - 1, 7, (unsigned long long) spins);
                 q_stamp(cx, b < cx.NB ? b : cx.NB - 1, 4);
             }
+            // nothing of this wave's is in flight any more (it only loads, and every load of the block has been used): said
+            // explicitly so that the wait-count pass carries a clean slate over the back edge
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         }
         return;
     }
@@ -463,6 +470,7 @@ __device__ __forceinline__ void q_h_wave(const GruQuadArgs &g, const QCtx &cx, c
 #pragma unroll
     for (int m = 0; m < 4; ++m) hreg[m] = ((const f32x4 *) g.hstate_in)[((size_t) (cx.mt0 + m) * kUnitTiles + u) * 64 + lane];
 
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the resident weights, bias and initial state are in (see q_x_wave)
     unsigned w0p = 0, w1p = 0;  // block b - 1's tile, not yet in its image (readers may still have been at it)
     for (int b = 0; b < cx.NB; ++b) {
         const int t = b >> 2, m = b & 3;
