@@ -41,8 +41,8 @@ constexpr int kQDG = 4;                               // depth of the pre-activa
 constexpr int kQA = KQ_QA;                            // operand fragments in flight (LDS -> register) in the MFMA loops
 constexpr int kQHsBytes = 9 * 1024;                   // one hidden-state operand image: 9 k-blocks in A-fragment order
 constexpr int kQOffHs = 0;                            // [4 m-tiles]: h_{t-1} while a block reads it, then h_t tile by tile
-constexpr int kQOffXs = 4 * kQHsBytes;                // [2][NBX] KiB (sized for NBX = 11)
-constexpr int kQOffGi = kQOffXs + 2 * 11 * 1024;      // [4 pairs][kQDG][3 gates][64 lanes][8 B]
+constexpr int kQOffXs = 4 * kQHsBytes;                // [3][NBX] KiB (sized for NBX = 11): blocks b, b + 1 and the one being staged
+constexpr int kQOffGi = kQOffXs + 3 * 11 * 1024;      // [4 pairs][kQDG][3 gates][64 lanes][8 B]
 constexpr int kQOffGh16 = kQOffGi + 4 * kQDG * 1536;  // [2][3][64][16 B]  unit tile 16: fp32 recurrent accumulators
 constexpr int kQOffW16x = kQOffGh16 + 2 * 3072;       // [3 gates][NBX] KiB  unit tile 16's W_ih (sized for NBX = 11)
 constexpr int kQOffW16h = kQOffW16x + 3 * 11 * 1024;  // [3 gates][9] KiB    unit tile 16's W_hh
@@ -264,11 +264,26 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
     };
 
     u32x2 gi16[3] = {u32x2{0, 0}, u32x2{0, 0}, u32x2{0, 0}};  // (wave 3) unit tile 16's fp16 pre-activations of the current step
+    // Staging of the x operand runs TWO blocks ahead: the fragments requested at the start of block b (for block b + 2) are
+    // written into the ring at the start of block b + 1, a whole block later -- a global load takes about a microsecond here,
+    // which is most of a block.
+    const float b16r = g.bih[(16 * 3 + 0) * 16 + cx.colq], b16z = g.bih[(16 * 3 + 1) * 16 + cx.colq],
+                b16n = g.bih[(16 * 3 + 2) * 16 + cx.colq];
+    frag_t st0 = w[0][0], st1 = w[0][0], st2 = w[0][0];
     auto do_block = [&](const int b, auto w16_tag) {
         constexpr bool kW16 = decltype(w16_tag)::value;
-        const int bn = b + 1 < cx.NB ? b + 1 : cx.NB - 1;
-        const frag_t s0 = *piece(bn, p0), s1 = *piece(bn, p1), s2 = *piece(bn, p2);  // in flight during the MFMAs
-        const frag_t *xa = (const frag_t *) (cx.smem + kQOffXs + (b & 1) * NBX * 1024);
+        if (b > 0) {  // (blocks 0 and 1 were staged by the prologue)
+            frag_t *xn = (frag_t *) (cx.smem + kQOffXs + ((b + 1) % 3) * NBX * 1024);
+            xn[p0 * 64 + lane] = st0;
+            xn[p1 * 64 + lane] = st1;
+            xn[p2 * 64 + lane] = st2;
+            q_flag_write(cx.flags + (kFXW + j) * 4, b + 2);
+        }
+        const int bn = b + 2 < cx.NB ? b + 2 : cx.NB - 1;
+        st0 = *piece(bn, p0);
+        st1 = *piece(bn, p1);
+        st2 = *piece(bn, p2);
+        const frag_t *xa = (const frag_t *) (cx.smem + kQOffXs + (b % 3) * NBX * 1024);
         f32x4 acc[3];
 #pragma unroll
         for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -289,50 +304,43 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
             q_x_mma16<NBX>(acc, xa, w16, lane);
 #pragma unroll
             for (int gt = 0; gt < 3; ++gt) {
-                const float b16 = g.bih[(16 * 3 + gt) * 16 + cx.colq];
+                const float b16 = gt == 0 ? b16r : gt == 1 ? b16z : b16n;
                 f32x4 v = acc[gt];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = v[i] + b16;
                 gi16[gt] = __builtin_bit_cast(u32x2, PBF16::to_gi(v));
             }
         }
-        frag_t *xn = (frag_t *) (cx.smem + kQOffXs + ((b + 1) & 1) * NBX * 1024);
-        xn[p0 * 64 + lane] = s0;
-        xn[p1 * 64 + lane] = s1;
-        xn[p2 * 64 + lane] = s2;
-        q_flag_write(cx.flags + (kFXW + j) * 4, b + 2);
     };
 
     if (j < 3) {
-        // Waves 0..2 also FILE the remote tiles of h: wave j the four tiles of workgroup (c + 1 + j) & 3.  In its block b it
-        // requests what h-block b - 1 reads (produced remotely in h-block b - 5, one or two blocks in the past since the x waves
-        // run three to four blocks ahead of the h waves), checks the tags after its own MFMAs and writes the words into the
-        // LDS image.
+        // Waves 0..2 also FILE the remote tiles of h: wave j the four tiles of workgroup (c + 1 + j) & 3 (wave 0: and unit tile
+        // 16 from the workgroup that serves it).  At the start of its block b it requests what h-block b - 1 reads (produced
+        // remotely in h-block b - 5, a few blocks in the past: the x waves run ahead of the h waves), and a block later, at the
+        // start of block b + 1, checks the tags and writes the words into the LDS image: the requests have a whole block to
+        // come back.
         const int rq = (c + 1 + j) & 3;
-        for (int b = 0; b < cx.NB + 1; ++b) {
-            const int gq = b - 1;
+        QGather q;
+        auto issue = [&](int bq) {
+            q_gather_load(g, cx, bq, 4 * rq, 1, q);
+            const size_t slot = ((size_t) (cx.mt0 + (bq & 3)) * 2 + (((bq >> 2) - 1) & 1)) * 17 + 16;
+            q.g16 = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc((const char *) g.xchg + slot * 1024, 1024), lane * 16u, 0, 16);
+        };
+        issue(4);  // (something harmless: nothing is filed before h-block 4)
+        for (int b = 0; b < cx.NB + 2; ++b) {
+            const int gq = b - 2;  // requested at the start of block b - 1
             const bool real = gq >= 4 && gq < cx.NB;
+            const bool real16 = real && j == 0 && (gq & 3) != c;
+            const int bs = b < cx.NB ? b : cx.NB - 1;
             // the x operand of this block is staged, the ring slot is free; the image of h-block gq was last read by h-block gq - 4
             const int need = b < cx.NB ? (cx.lane5 < 4 ? b + 1
                                           : cx.lane5 == kFGC + j ? b + 1 - kQDG
                                           : (cx.lane5 >= kFHM && cx.lane5 < kFHM + 4) ? gq - 3
                                                                                        : INT_MIN)
                                        : ((cx.lane5 >= kFHM && cx.lane5 < kFHM + 4) ? gq - 3 : INT_MIN);
-            q_stamp(cx, b < cx.NB ? b : cx.NB - 1, 0);
+            q_stamp(cx, bs, 0);
             if (!q_wait(cx, need, 0x10000000u | (unsigned) (j << 24) | (unsigned) b, b < cx.NB ? b : -1)) return;
-            q_stamp(cx, b < cx.NB ? b : cx.NB - 1, 1);
-            QGather q;
-            q_gather_load(g, cx, real ? gq : 4 + (b & 3), 4 * rq, 1, q);
-            // wave 0 also fetches unit tile 16 of the m-tile from the workgroup that serves it (nothing to fetch when that is
-            // this one: kFH16 covers it)
-            const bool real16 = real && j == 0 && (gq & 3) != c;
-            {
-                const int bq = real ? gq : 4 + (b & 3);
-                const size_t slot = ((size_t) (cx.mt0 + (bq & 3)) * 2 + (((bq >> 2) - 1) & 1)) * 17 + 16;
-                q.g16 = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc((const char *) g.xchg + slot * 1024, 1024), lane * 16u, 0, 16);
-            }
-            if (b < cx.NB) do_block(b, std::false_type{});
-            q_stamp(cx, b < cx.NB ? b : cx.NB - 1, 3);
+            q_stamp(cx, bs, 1);
             if (real) {
                 int spins = 0;
                 auto valid = [&]() {
@@ -349,9 +357,7 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
                     }
                     __builtin_amdgcn_s_sleep(2);
                     asm volatile("" ::: "memory");
-                    q_gather_load(g, cx, gq, 4 * rq, 1, q);
-                    const size_t slot = ((size_t) (cx.mt0 + (gq & 3)) * 2 + (((gq >> 2) - 1) & 1)) * 17 + 16;
-                    q.g16 = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc((const char *) g.xchg + slot * 1024, 1024), lane * 16u, 0, 16);
+                    issue(gq);
                 }
                 q_gather_file(cx, gq, 4 * rq, 1, q);
                 if (real16) {
@@ -361,12 +367,16 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
                 }
                 q_flag_write(cx.flags + (kFHG + j) * 4, gq + 1);
                 if (j == 0) q_flag_write(cx.flags + (kFHG + 3) * 4, gq + 1);
-                q_note(cx, b < cx.NB ? b : cx.NB - 1, 7, (unsigned long long) spins);
-                q_stamp(cx, b < cx.NB ? b : cx.NB - 1, 4);
+                q_note(cx, bs, 7, (unsigned long long) spins);
             }
-            // nothing of this wave's is in flight any more (it only loads, and every load of the block has been used): said
-            // explicitly so that the wait-count pass carries a clean slate over the back edge
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            q_stamp(cx, bs, 4);
+            {
+                const int gn = b - 1;
+                asm volatile("" ::: "memory");
+                issue(gn >= 4 && gn < cx.NB ? gn : 4 + (b & 3));
+            }
+            if (b < cx.NB) do_block(b, std::false_type{});
+            q_stamp(cx, bs, 3);
         }
         return;
     }
@@ -582,12 +592,13 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad_kernel(GruQuadArgs g
         *(unsigned *) img = w0;
         *(unsigned *) (img + 16) = w1;
     }
-    for (int i = wave; i < NBX; i += kQWaves) {
-        const bf16x8 *src = i < NB0 ? (const bf16x8 *) g.a0 + ((size_t) cx.mt0 * NB0 + i) * 64
-                                    : (const bf16x8 *) g.a1 + ((size_t) cx.mt0 * 9 + (i - NB0)) * 64;
+    for (int i = wave; i < 2 * NBX; i += kQWaves) {  // blocks 0 and 1 (= m-tiles 0 and 1 of step 0; T = 1 has four blocks too)
+        const int blk = i / NBX, k = i % NBX;
+        const bf16x8 *src = k < NB0 ? (const bf16x8 *) g.a0 + ((size_t) (cx.mt0 + blk) * NB0 + k) * 64
+                                    : (const bf16x8 *) g.a1 + ((size_t) (cx.mt0 + blk) * 9 + (k - NB0)) * 64;
         ((bf16x8 *) (smem + kQOffXs))[i * 64 + lane] = src[lane];
     }
-    if (tid < 4) ((int *) (smem + kQOffFlags))[kFXW + tid] = 1;
+    if (tid < 4) ((int *) (smem + kQOffFlags))[kFXW + tid] = 2;
     __syncthreads();
     if (wave < 4)
         q_x_wave<NB0>(g, cx, wave);
