@@ -63,6 +63,11 @@ enum {
     kFAbort = 31,
 };
 
+// developer ablations (timing experiments, results are garbage): 1 no remote gather, 2 no x staging loads, 4 no global stores
+// of h, 8 no gate math, 16 no MFMAs
+#ifndef KQ_ABL
+#define KQ_ABL 0
+#endif
 constexpr int kQSpinLimit = 1 << 21;     // LDS polls (~0.2 s)
 constexpr int kQGatherLimit = 1 << 18;   // global polls (~0.3 s)
 
@@ -137,6 +142,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // the bf16 configuration's gate arithmetic -- operation for operation what gru_resident8_kernel does
 __device__ __forceinline__ f32x4 q_gates(const f32x4 (&acc)[3], u32x2 pr, u32x2 pz, u32x2 pn, float br, float bz, float bn,
                                          const f32x4 &hprev) {
+    if (KQ_ABL & 8) return acc[0] + acc[1] + acc[2] + hprev;
     const f32x2 vbr = {br, br}, vbz = {bz, bz}, vbn = {bn, bn};
     f32x4 hnew;
 #pragma unroll
@@ -158,11 +164,15 @@ __device__ __forceinline__ f32x4 q_gates(const f32x4 (&acc)[3], u32x2 pr, u32x2 
 // h_t of unit tile u, m-tile (local) m, as this lane's two packed operand words: to the other workgroups as granules and to the
 // hidden sequence in HBM.  The caller writes the words into the m-tile's LDS image (q_image_write) once nobody reads it.
 __device__ __forceinline__ void q_publish(const GruQuadArgs &g, const QCtx &cx, int t, int m, int u, unsigned w0, unsigned w1) {
+    if (KQ_ABL & 4) return;
     const int mt = cx.mt0 + m;
     const unsigned tag = cx.tag_base | (unsigned) (t + 1);
     const __amdgpu_buffer_rsrc_t gr =
         make_rsrc((char *) g.xchg + (((size_t) mt * 2 + (t & 1)) * 17 + u) * 1024, 1024);
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{tag, w0, tag, w1}, gr, cx.lane * 16u, 0, 16 /* sc1: write through */);
+#ifndef KQ_STORE_AUX
+#define KQ_STORE_AUX 16
+#endif
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{tag, w0, tag, w1}, gr, cx.lane * 16u, 0, KQ_STORE_AUX /* 16 = sc1: write through */);
     const __amdgpu_buffer_rsrc_t hr =
         make_rsrc((char *) g.hseq + ((size_t) t * cx.mtiles + mt) * kQHsBytes + q_tile_off(u), 512);
     __builtin_amdgcn_raw_buffer_store_b32(w0, hr, (unsigned) cx.lane_off, 0, 0);
@@ -218,7 +228,8 @@ __device__ __forceinline__ void q_x_mma(f32x4 (&acc)[3], const bf16x8 *xa, const
     for (int blk = 0; blk < NBX; ++blk) {
         const bf16x8 a = qa[blk % kQA];
 #pragma unroll
-        for (int gt = 0; gt < 3; ++gt) acc[gt] = PBF16::mma(a, w[gt][blk], acc[gt]);
+        for (int gt = 0; gt < 3; ++gt)
+            if (!(KQ_ABL & 16)) acc[gt] = PBF16::mma(a, w[gt][blk], acc[gt]);
         if (blk + kQA < NBX) qa[blk % kQA] = xa[(blk + kQA) * 64 + lane];
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -231,7 +242,8 @@ __device__ __forceinline__ void q_x_mma16(f32x4 (&acc)[3], const bf16x8 *xa, con
     for (int blk = 0; blk < NBX; ++blk) {
         const bf16x8 a = xa[blk * 64 + lane];
 #pragma unroll
-        for (int gt = 0; gt < 3; ++gt) acc[gt] = PBF16::mma(a, w16[(gt * NBX + blk) * 64 + lane], acc[gt]);
+        for (int gt = 0; gt < 3; ++gt)
+            if (!(KQ_ABL & 16)) acc[gt] = PBF16::mma(a, w16[(gt * NBX + blk) * 64 + lane], acc[gt]);
     }
 }
 
@@ -280,9 +292,11 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
             q_flag_write(cx.flags + (kFXW + j) * 4, b + 2);
         }
         const int bn = b + 2 < cx.NB ? b + 2 : cx.NB - 1;
-        st0 = *piece(bn, p0);
-        st1 = *piece(bn, p1);
-        st2 = *piece(bn, p2);
+        if (!(KQ_ABL & 2)) {
+            st0 = *piece(bn, p0);
+            st1 = *piece(bn, p1);
+            st2 = *piece(bn, p2);
+        }
         const frag_t *xa = (const frag_t *) (cx.smem + kQOffXs + (b % 3) * NBX * 1024);
         f32x4 acc[3];
 #pragma unroll
@@ -320,8 +334,9 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
         // start of block b + 1, checks the tags and writes the words into the LDS image: the requests have a whole block to
         // come back.
         const int rq = (c + 1 + j) & 3;
-        QGather q;
+        QGather q = {};
         auto issue = [&](int bq) {
+            if (KQ_ABL & 1) return;
             q_gather_load(g, cx, bq, 4 * rq, 1, q);
             const size_t slot = ((size_t) (cx.mt0 + (bq & 3)) * 2 + (((bq >> 2) - 1) & 1)) * 17 + 16;
             q.g16 = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc((const char *) g.xchg + slot * 1024, 1024), lane * 16u, 0, 16);
@@ -344,6 +359,7 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
             if (real) {
                 int spins = 0;
                 auto valid = [&]() {
+                    if (KQ_ABL & 1) return true;
                     if (!q_gather_valid(cx, gq, q)) return false;
                     const unsigned tag = cx.tag_base | (unsigned) (gq >> 2);
                     return !real16 || __builtin_amdgcn_ballot_w64(q.g16[0] != tag || q.g16[2] != tag) == 0;
@@ -457,8 +473,9 @@ __device__ __forceinline__ void q_h_mma(f32x4 (&acc)[3], f32x4 &a16, const bf16x
     for (int blk = 0; blk < 9; ++blk) {
         const bf16x8 a = qa[blk % kQA];
 #pragma unroll
-        for (int gt = 0; gt < 3; ++gt) acc[gt] = PBF16::mma(a, w[blk * 3 + gt], acc[gt]);
-        if (kW16) a16 = PBF16::mma(a, qw[blk % kQA], a16);
+        for (int gt = 0; gt < 3; ++gt)
+            if (!(KQ_ABL & 16)) acc[gt] = PBF16::mma(a, w[blk * 3 + gt], acc[gt]);
+        if (kW16 && !(KQ_ABL & 16)) a16 = PBF16::mma(a, qw[blk % kQA], a16);
         if (blk + kQA < 9) {
             qa[blk % kQA] = ha[(blk + kQA) * 64 + lane];
             if (kW16) qw[blk % kQA] = w16[(blk + kQA) * 64 + lane];

@@ -13,7 +13,7 @@ import koala_amd  # noqa: E402
 from koala_amd import params  # noqa: E402
 from koala_amd.workload import synth_streams  # noqa: E402
 
-DEV = koala_amd.developer_library_path()
+DEV = os.environ.get("QUAD_LIB") or koala_amd.developer_library_path()
 
 
 def make(B, T, quad, model):
