@@ -4,27 +4,30 @@
 //
 // Decomposition.  Four workgroups (same XCD by dispatch order: blocks b, b + 8, b + 16, b + 24) own four m-tiles = 64 streams.
 // Workgroup c keeps, for ALL T steps, the columns of W_ih and W_hh of hidden units 64 c .. 64 c + 63 (unit tiles 4 c .. 4 c + 3
-// = k-blocks 2 c, 2 c + 1 of the hidden state) in registers; unit tile 16 (units 256 .. 270) is kept by every workgroup and
-// served by workgroup c for m-tile c.  A "block" is (step t, m-tile m), walked in the order b = 4 t + m by everybody.
-//   x waves 0..3  wave j: W_ih of unit tile 4 c + j (3 x NBX fragments).  Per block: the 3 x NBX MFMAs of x_t . W_ih for that tile,
-//                 + b_ih, rounded to fp16 (the storage type of the unfused path's `gi`, so the arithmetic is the same bit for
-//                 bit), into a 4-deep LDS ring for its partner h wave.  They do not depend on h: they run up to 4 blocks ahead
-//                 and their MFMAs fill the matrix pipe while the partner's gate VALU work runs.  They also stage x_t in LDS
-//                 (each wave fetches a quarter of the k-blocks one block ahead).  Wave 3 also serves unit tile 16: its input
-//                 projection in the blocks with m = c (weights from LDS) and its gate math.
-//   h waves 4..7  wave j: W_hh of unit tile 4 c + j (27 fragments).  Per block: wait for h_{t-1} of the m-tile to be complete in
-//                 LDS, 27 MFMAs (waves 0..2: + one gate of tile 16 when m = c, weights from LDS), gates, h_t of its tile -> the
-//                 m-tile's LDS image (once every wave has finished READING it), -> the other three workgroups as granules, ->
-//                 the hidden sequence in HBM (the next kernel's A operand).  Before a block's MFMAs it requests the granules
-//                 the NEXT block needs from one of the other workgroups; after its gates it checks their tags and files them
-//                 into the LDS image (re-polling only if they were late).
-// Hand-off (MI355X guide, "R2"): a lane's 16-byte store carries two self-tagged 8-byte granules {tag, 2 x bf16}; tag = launch
-// serial << 12 | step + 1.  No flag, no fence, no drain: the data is its own flag; stores write through (sc1), loads bypass L1
-// (sc1).  Slots alternate with the step's parity; a slot is rewritten only after every consumer has used it (by data flow:
-// producing h_{t+2} needs all of h_{t+1}, which needed every consumer's h_t to be complete).
-// Synchronisation inside a workgroup: monotonic block counters in LDS, written and polled with explicit ds instructions (a
-// wave's DS operations execute in order: whoever sees a counter sees the data written before it); no barrier in the loop.
-// Every wait is bounded: on overrun the workgroup raises an abort word, records a code in GruQuadArgs::err and leaves.
+// = k-blocks 2 c, 2 c + 1 of the hidden state) in registers; unit tile 16 (units 256 .. 270) is kept by every workgroup (in
+// LDS) and served by workgroup c for m-tile c.  A "block" is (step t, m-tile m), numbered b = 4 t + m.
+// The workgroup advances in PHASES separated by one s_barrier; in phase p
+//   x waves 0..3  (wave j: W_ih of unit tile 4 c + j, 3 x NBX fragments in registers) compute x . W_ih of block p + 1 -- it does
+//                 not depend on h --, add b_ih, round to fp16 (the storage type of the two-kernel form's `gi`: the arithmetic
+//                 is the same bit for bit) and leave it in LDS for their partner; they stage the x operand two blocks ahead
+//                 (each wave a quarter of the k-blocks); waves 0..2 FILE the other workgroups' tiles of the h that block
+//                 p + 1 reads into its LDS image (requested from the exchange buffer a phase earlier, tags checked now);
+//                 wave 3 serves unit tile 16: its input projection where m = c (weights from LDS) and its gate math;
+//   h waves 4..7  (wave j: W_hh of unit tile 4 c + j, 27 fragments in registers) do block p: 27 MFMAs against the image of
+//                 h_{t-1} (waves 0..2 one gate of tile 16 as well where m = c), gates, and send h_t of their tile to the other
+//                 three workgroups (granules) and to the hidden sequence in HBM; the tile enters the LDS image at the start
+//                 of the next phase, when nobody reads that image any more.
+// One wave of each kind shares a SIMD: the x wave's MFMAs run under its partner's gate arithmetic.
+// Hand-off between workgroups (MI355X guide, "R2"): a lane's 16-byte store carries two self-tagged 8-byte granules {tag, 2 x
+// bf16}; tag = launch serial << 12 | step + 1.  No flag, no fence, no drain: the data is its own flag; loads bypass L1 (sc1).
+// Slots alternate with the step's parity; a slot is rewritten only after every consumer has used it (by data flow: producing
+// h_{t+2} needs all of h_{t+1}, which needed every consumer's h_t to be complete).  A block's output is needed four phases
+// later; it is requested two phases and checked three phases after it was produced.
+// Every wait for another workgroup is bounded: on overrun the wave records a code in GruQuadArgs::err, stops polling and runs
+// the remaining phases on whatever it has (the call's results are invalid and the host is told so).
+// (The first form of this kernel synchronised its waves through counters in LDS instead of barriers: bit-identical results,
+// 375 us per layer at the bench shape against 278 us for the two-kernel form -- its synchronisation skeleton alone, with
+// MFMAs, gate arithmetic and memory traffic compiled out, took 194 us.  History: commit "fused kernel (flag-synchronised form)".)
 #include "kns_device.hpp"
 
 #include <limits.h>
@@ -34,59 +37,31 @@
 namespace kns {
 
 constexpr int kQWaves = 8;
-constexpr int kQDG = 4;                               // depth of the pre-activation rings, in blocks
 #ifndef KQ_QA
 #define KQ_QA 4
 #endif
 constexpr int kQA = KQ_QA;                            // operand fragments in flight (LDS -> register) in the MFMA loops
 constexpr int kQHsBytes = 9 * 1024;                   // one hidden-state operand image: 9 k-blocks in A-fragment order
 constexpr int kQOffHs = 0;                            // [4 m-tiles]: h_{t-1} while a block reads it, then h_t tile by tile
-constexpr int kQOffXs = 4 * kQHsBytes;                // [3][NBX] KiB (sized for NBX = 11): blocks b, b + 1 and the one being staged
-constexpr int kQOffGi = kQOffXs + 3 * 11 * 1024;      // [4 pairs][kQDG][3 gates][64 lanes][8 B]
-constexpr int kQOffGh16 = kQOffGi + 4 * kQDG * 1536;  // [2][3][64][16 B]  unit tile 16: fp32 recurrent accumulators
+constexpr int kQOffXs = 4 * kQHsBytes;                // [3][NBX] KiB (sized for NBX = 11): x of three consecutive blocks
+constexpr int kQOffGi = kQOffXs + 3 * 11 * 1024;      // [2][4 pairs][3 gates][64 lanes][8 B]: fp16 pre-activations
+constexpr int kQOffGh16 = kQOffGi + 2 * 4 * 1536;     // [2][3][64][16 B]  unit tile 16: fp32 recurrent accumulators
 constexpr int kQOffW16x = kQOffGh16 + 2 * 3072;       // [3 gates][NBX] KiB  unit tile 16's W_ih (sized for NBX = 11)
 constexpr int kQOffW16h = kQOffW16x + 3 * 11 * 1024;  // [3 gates][9] KiB    unit tile 16's W_hh
-constexpr int kQOffFlags = kQOffW16h + 27 * 1024;     // 32 words
-constexpr int kQLds = kQOffFlags + 128;
-
-// flag words (all count blocks or steps upwards from 0)
-enum {
-    kFXW = 0,     // [4] x wave j has staged its share of x for blocks < value
-    kFGI = 4,     // [4] x wave j has produced the pre-activations of blocks < value
-    kFGC = 8,     // [4] h wave j has consumed the pre-activations of blocks < value
-    kFHL = 12,    // [4] h wave j has written its tile of h for blocks < value
-    kFHG = 16,    // [4] h wave j has filed the remote tiles it is responsible for, for the h that blocks < value READ
-    kFHM = 20,    // [4] h wave j has finished READING the operand images (its MFMAs) of blocks < value
-    kFH16 = 28,   //     unit tile 16 of h (m-tile c) is complete for steps < value
-    kFGH16 = 24,  // [3] gate j of unit tile 16's recurrent accumulators is there for steps < value
-    kFG16C = 27,  //     unit tile 16's gate math has consumed steps < value
-    kFAbort = 31,
-};
+constexpr int kQLds = kQOffW16h + 27 * 1024;
 
 // developer ablations (timing experiments, results are garbage): 1 no remote gather, 2 no x staging loads, 4 no global stores
 // of h, 8 no gate math, 16 no MFMAs
 #ifndef KQ_ABL
 #define KQ_ABL 0
 #endif
-constexpr int kQSpinLimit = 1 << 21;     // LDS polls (~0.2 s)
-constexpr int kQGatherLimit = 1 << 18;   // global polls (~0.3 s)
-
-__device__ __forceinline__ int q_flags_read(unsigned addr) {
-    int v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-    return v;
-}
-__device__ __forceinline__ void q_flag_write(unsigned addr, int v) {
-    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
+constexpr int kQGatherLimit = 1 << 18;   // polls of the exchange buffer (~0.3 s)
 
 struct QCtx {
     unsigned long long *dbg;  // this wave's stamp rows ([block][8]) or null
     char *smem;
-    unsigned flags;       // LDS address of flag word 0
-    unsigned flags_lane;  // LDS address of flag word (lane & 31)
     unsigned *err;
-    int lane, lane5, colq;
+    int lane, colq;
     int c;                // workgroup's place in its quad
     int mt0;              // first m-tile of the quad
     int T, mtiles, NB;    // NB = 4 T blocks
@@ -95,34 +70,16 @@ struct QCtx {
     int lane_off;         // byte offset of this lane's first packed word inside a unit tile's half k-block (second: + 16)
 };
 
-// developer instrumentation: s_memtime of one workgroup's waves at fixed points of every block (null in production)
+// developer instrumentation: s_memtime of one workgroup's waves at fixed points of every phase (null in production)
 __device__ __forceinline__ void q_stamp(const QCtx &cx, int b, int slot) {
-    if (cx.dbg && cx.lane == 0) cx.dbg[b * 8 + slot] = __builtin_amdgcn_s_memtime();
+    if (cx.dbg && cx.lane == 0 && b >= 0 && b < cx.NB) cx.dbg[b * 8 + slot] = __builtin_amdgcn_s_memtime();
 }
 __device__ __forceinline__ void q_note(const QCtx &cx, int b, int slot, unsigned long long v) {
-    if (cx.dbg && cx.lane == 0) cx.dbg[b * 8 + slot] = v;
+    if (cx.dbg && cx.lane == 0 && b >= 0 && b < cx.NB) cx.dbg[b * 8 + slot] = v;
 }
 
-__device__ __forceinline__ void q_abort(const QCtx &cx, unsigned code) {
-    q_flag_write(cx.flags + kFAbort * 4, 1);
-    if (cx.lane == 0) atomicCAS(cx.err, 0u, code);
-}
-
-// waits until flag[i] >= need(i) for every word (need is this lane's requirement for word lane & 31; INT_MIN = none)
-__device__ __forceinline__ bool q_wait(const QCtx &cx, int need, unsigned code, int dbg_block = -1) {
-    for (int spin = 0;; ++spin) {
-        const int v = q_flags_read(cx.flags_lane);
-        if (__builtin_amdgcn_readlane(v, kFAbort) != 0) return false;
-        const unsigned long long lag = __builtin_amdgcn_ballot_w64(v < need);
-        if (spin == 0 && dbg_block >= 0) q_note(cx, dbg_block, 6, lag & 0xffffffffull);  // which counters were behind at first look
-        if (lag == 0) return true;
-        if (spin > kQSpinLimit) {
-            q_abort(cx, code);
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
+// every LDS access of this wave has been performed; then the workgroup's barrier
+__device__ __forceinline__ void q_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // a unit tile of h in C-fragment order (lane: column colq, rows 4 q .. 4 q + 3) -> this lane's two packed words of the A
 // operand: neighbouring lanes trade two values so that a word holds two consecutive k of one row
@@ -262,9 +219,15 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
         bi[gt] = g.bih[(u * 3 + gt) * 16 + cx.colq];
     }
     const frag_t *w16 = (const frag_t *) (cx.smem + kQOffW16x);
+    // (wave 3) unit tile 16: biases, fp32 state of m-tile c
+    const float b16r = g.bih[(16 * 3 + 0) * 16 + cx.colq], b16z = g.bih[(16 * 3 + 1) * 16 + cx.colq],
+                b16n = g.bih[(16 * 3 + 2) * 16 + cx.colq];
+    const float bh16r = g.bhh[(16 * 3 + 0) * 16 + cx.colq], bh16z = g.bhh[(16 * 3 + 1) * 16 + cx.colq],
+                bh16n = g.bhh[(16 * 3 + 2) * 16 + cx.colq];
+    f32x4 h16 = ((const f32x4 *) g.hstate_in)[((size_t) (cx.mt0 + c) * kUnitTiles + 16) * 64 + lane];
     // The resident weights have arrived before the loop is entered -- said explicitly: hipcc's wait-count pass otherwise merges
-    // "still in flight" from the loop's entry edge into the loop header and makes every block's MFMAs wait for the vector-memory
-    // operations of the block before (vmcnt counts them all).
+    // "still in flight" from the loop's entry edge into the loop header and makes every phase's MFMAs wait for the
+    // vector-memory operations of the phase before (vmcnt counts them all).
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 
     // this wave's share of a block's x operand: k-blocks j, j + 4, j + 8 (clamped: an extra copy of the last one is harmless)
@@ -274,36 +237,33 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
         if (NB0 > 0 && i < NB0) return (const frag_t *) g.a0 + (mtg * NB0 + i) * 64 + lane;
         return (const frag_t *) g.a1 + (mtg * 9 + (i - NB0)) * 64 + lane;
     };
+    frag_t st0, st1, st2;
+    auto stage_load = [&](int blk) {
+        const int bn = blk < cx.NB ? blk : cx.NB - 1;
+        if (KQ_ABL & 2) {
+            st0 = st1 = st2 = w[0][0];
+            return;
+        }
+        st0 = *piece(bn, p0);
+        st1 = *piece(bn, p1);
+        st2 = *piece(bn, p2);
+    };
+    auto stage_write = [&](int blk) {
+        frag_t *xn = (frag_t *) (cx.smem + kQOffXs + (blk % 3) * NBX * 1024);
+        xn[p0 * 64 + lane] = st0;
+        xn[p1 * 64 + lane] = st1;
+        xn[p2 * 64 + lane] = st2;
+    };
 
     u32x2 gi16[3] = {u32x2{0, 0}, u32x2{0, 0}, u32x2{0, 0}};  // (wave 3) unit tile 16's fp16 pre-activations of the current step
-    // Staging of the x operand runs TWO blocks ahead: the fragments requested at the start of block b (for block b + 2) are
-    // written into the ring at the start of block b + 1, a whole block later -- a global load takes about a microsecond here,
-    // which is most of a block.
-    const float b16r = g.bih[(16 * 3 + 0) * 16 + cx.colq], b16z = g.bih[(16 * 3 + 1) * 16 + cx.colq],
-                b16n = g.bih[(16 * 3 + 2) * 16 + cx.colq];
-    frag_t st0 = w[0][0], st1 = w[0][0], st2 = w[0][0];
-    auto do_block = [&](const int b, auto w16_tag) {
-        constexpr bool kW16 = decltype(w16_tag)::value;
-        if (b > 0) {  // (blocks 0 and 1 were staged by the prologue)
-            frag_t *xn = (frag_t *) (cx.smem + kQOffXs + ((b + 1) % 3) * NBX * 1024);
-            xn[p0 * 64 + lane] = st0;
-            xn[p1 * 64 + lane] = st1;
-            xn[p2 * 64 + lane] = st2;
-            q_flag_write(cx.flags + (kFXW + j) * 4, b + 2);
-        }
-        const int bn = b + 2 < cx.NB ? b + 2 : cx.NB - 1;
-        if (!(KQ_ABL & 2)) {
-            st0 = *piece(bn, p0);
-            st1 = *piece(bn, p1);
-            st2 = *piece(bn, p2);
-        }
-        const frag_t *xa = (const frag_t *) (cx.smem + kQOffXs + (b % 3) * NBX * 1024);
+    // x . W_ih of block q -> the ring slot its partner reads in phase q (wave 3: and unit tile 16's where the block's m = c)
+    auto project = [&](const int q) {
+        const frag_t *xa = (const frag_t *) (cx.smem + kQOffXs + (q % 3) * NBX * 1024);
         f32x4 acc[3];
 #pragma unroll
         for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
         q_x_mma<NBX>(acc, xa, w, lane);
-        q_stamp(cx, b, 2);
-        char *ring = cx.smem + kQOffGi + ((j * kQDG + (b & (kQDG - 1))) * 3) * 512 + lane * 8;
+        char *ring = cx.smem + kQOffGi + (((q & 1) * 4 + j) * 3) * 512 + lane * 8;
 #pragma unroll
         for (int gt = 0; gt < 3; ++gt) {
             f32x4 v = acc[gt];
@@ -311,8 +271,7 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
             for (int i = 0; i < 4; ++i) v[i] = v[i] + bi[gt];
             *(f16x4 *) (ring + gt * 512) = PBF16::to_gi(v);
         }
-        q_flag_write(cx.flags + (kFGI + j) * 4, b + 1);
-        if (kW16) {
+        if (j == 3 && (q & 3) == c) {
 #pragma unroll
             for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
             q_x_mma16<NBX>(acc, xa, w16, lane);
@@ -327,138 +286,87 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
         }
     };
 
-    if (j < 3) {
-        // Waves 0..2 also FILE the remote tiles of h: wave j the four tiles of workgroup (c + 1 + j) & 3 (wave 0: and unit tile
-        // 16 from the workgroup that serves it).  At the start of its block b it requests what h-block b - 1 reads (produced
-        // remotely in h-block b - 5, a few blocks in the past: the x waves run ahead of the h waves), and a block later, at the
-        // start of block b + 1, checks the tags and writes the words into the LDS image: the requests have a whole block to
-        // come back.
-        const int rq = (c + 1 + j) & 3;
-        QGather q = {};
-        auto issue = [&](int bq) {
-            if (KQ_ABL & 1) return;
-            q_gather_load(g, cx, bq, 4 * rq, 1, q);
-            const size_t slot = ((size_t) (cx.mt0 + (bq & 3)) * 2 + (((bq >> 2) - 1) & 1)) * 17 + 16;
-            q.g16 = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc((const char *) g.xchg + slot * 1024, 1024), lane * 16u, 0, 16);
-        };
-        issue(4);  // (something harmless: nothing is filed before h-block 4)
-        for (int b = 0; b < cx.NB + 2; ++b) {
-            const int gq = b - 2;  // requested at the start of block b - 1
-            const bool real = gq >= 4 && gq < cx.NB;
-            const bool real16 = real && j == 0 && (gq & 3) != c;
-            const int bs = b < cx.NB ? b : cx.NB - 1;
-            // the x operand of this block is staged, the ring slot is free; the image of h-block gq was last read by h-block gq - 4
-            const int need = b < cx.NB ? (cx.lane5 < 4 ? b + 1
-                                          : cx.lane5 == kFGC + j ? b + 1 - kQDG
-                                          : (cx.lane5 >= kFHM && cx.lane5 < kFHM + 4) ? gq - 3
-                                                                                       : INT_MIN)
-                                       : ((cx.lane5 >= kFHM && cx.lane5 < kFHM + 4) ? gq - 3 : INT_MIN);
-            q_stamp(cx, bs, 0);
-            if (!q_wait(cx, need, 0x10000000u | (unsigned) (j << 24) | (unsigned) b, b < cx.NB ? b : -1)) return;
-            q_stamp(cx, bs, 1);
-            if (real) {
-                int spins = 0;
-                auto valid = [&]() {
-                    if (KQ_ABL & 1) return true;
-                    if (!q_gather_valid(cx, gq, q)) return false;
-                    const unsigned tag = cx.tag_base | (unsigned) (gq >> 2);
-                    return !real16 || __builtin_amdgcn_ballot_w64(q.g16[0] != tag || q.g16[2] != tag) == 0;
-                };
-                while (!valid()) {
-                    const int v = q_flags_read(cx.flags_lane);
-                    if (__builtin_amdgcn_readlane(v, kFAbort) != 0) return;
-                    if (++spins > kQGatherLimit) {
-                        q_abort(cx, 0x30000000u | (unsigned) (j << 24) | (unsigned) gq);
-                        return;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                    asm volatile("" ::: "memory");
-                    issue(gq);
+    // remote tiles of h: wave j < 3 the four tiles of workgroup (c + 1 + j) & 3, wave 0 also unit tile 16 from the workgroup
+    // that serves it for the m-tile (nothing to fetch when that is this workgroup)
+    const int rq = (c + 1 + j) & 3;
+    QGather q = {};
+    bool dead = false;  // gave up on the exchange buffer: no more polling, the call is reported as failed
+    auto request = [&](int bq) {  // what h-block bq reads (redirected to something harmless where there is nothing to get)
+        if ((KQ_ABL & 1) || j == 3) return;
+        const int br = bq >= 4 && bq < cx.NB ? bq : 4 + (bq & 3);
+        q_gather_load(g, cx, br, 4 * rq, 1, q);
+        const size_t slot = ((size_t) (cx.mt0 + (br & 3)) * 2 + (((br >> 2) - 1) & 1)) * 17 + 16;
+        q.g16 = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc((const char *) g.xchg + slot * 1024, 1024), lane * 16u, 0, 16);
+    };
+    auto file = [&](int bq) {  // requested a phase ago
+        if (j == 3 || bq < 4 || bq >= cx.NB) return;
+        const bool real16 = j == 0 && (bq & 3) != c;
+        int spins = 0;
+        if (!(KQ_ABL & 1) && !dead) {
+            const unsigned tag = cx.tag_base | (unsigned) (bq >> 2);
+            while (!(q_gather_valid(cx, bq, q) &&
+                     (!real16 || __builtin_amdgcn_ballot_w64(q.g16[0] != tag || q.g16[2] != tag) == 0))) {
+                if (++spins > kQGatherLimit) {
+                    if (lane == 0) atomicCAS(cx.err, 0u, 0x30000000u | (unsigned) (j << 24) | (unsigned) bq);
+                    dead = true;
+                    break;
                 }
-                q_gather_file(cx, gq, 4 * rq, 1, q);
-                if (real16) {
-                    char *img = cx.smem + kQOffHs + (gq & 3) * kQHsBytes + cx.lane_off + q_tile_off(16);
-                    *(unsigned *) img = q.g16[1];
-                    *(unsigned *) (img + 16) = q.g16[3];
-                }
-                q_flag_write(cx.flags + (kFHG + j) * 4, gq + 1);
-                if (j == 0) q_flag_write(cx.flags + (kFHG + 3) * 4, gq + 1);
-                q_note(cx, bs, 7, (unsigned long long) spins);
-            }
-            q_stamp(cx, bs, 4);
-            {
-                const int gn = b - 1;
+                __builtin_amdgcn_s_sleep(2);
                 asm volatile("" ::: "memory");
-                issue(gn >= 4 && gn < cx.NB ? gn : 4 + (b & 3));
+                request(bq);
             }
-            if (b < cx.NB) do_block(b, std::false_type{});
-            q_stamp(cx, bs, 3);
         }
-        return;
-    }
+        q_gather_file(cx, bq, 4 * rq, 1, q);
+        if (real16) {
+            char *img = cx.smem + kQOffHs + (bq & 3) * kQHsBytes + cx.lane_off + q_tile_off(16);
+            *(unsigned *) img = q.g16[1];
+            *(unsigned *) (img + 16) = q.g16[3];
+        }
+        q_note(cx, bq, 7, (unsigned long long) spins);
+    };
 
-    // ---- wave 3: its own blocks (with unit tile 16's input projection where m = c), and unit tile 16's gate math as soon as
-    // the h waves have delivered a step's recurrent accumulators -- whichever is ready, never blocking on one while the other
-    // could run
-    const float bh16r = g.bhh[(16 * 3 + 0) * 16 + cx.colq], bh16z = g.bhh[(16 * 3 + 1) * 16 + cx.colq],
-                bh16n = g.bhh[(16 * 3 + 2) * 16 + cx.colq];
-    f32x4 h16 = ((const f32x4 *) g.hstate_in)[((size_t) (cx.mt0 + c) * kUnitTiles + 16) * 64 + lane];
-    int b = 0, t16 = 0, spin = 0;
-    while (b < cx.NB || t16 < cx.T) {
-        const int v = q_flags_read(cx.flags_lane);
-        if (__builtin_amdgcn_readlane(v, kFAbort) != 0) return;
-        // gate math of step t16: this wave has been through block (t16, c) (gi16 holds that step), the three recurrent
-        // accumulators are in LDS, and every h wave has finished reading the image the result goes into
-        const int b16 = 4 * t16 + c;
-        const bool late16 = (cx.lane5 >= kFGH16 && cx.lane5 < kFGH16 + 3) ? v < t16 + 1
-                            : ((cx.lane5 >= kFHM && cx.lane5 < kFHM + 4) ? v < b16 + 1 : false);
-        if (t16 < cx.T && b > b16 && __builtin_amdgcn_ballot_w64(late16) == 0) {
-            const int t = t16;
+    // ---- phase -1: blocks 0, 1, 2 of x are staged (kernel prologue); block 0's pre-activations, block 3's x on its way
+    stage_load(3);
+    project(0);
+    request(4);  // (nothing real before h-block 4; keeps the loop uniform)
+    q_barrier();
+    for (int p = 0; p <= cx.NB; ++p) {
+        q_stamp(cx, p, 0);
+        // x of block p + 3: requested a phase ago, into the ring now; block p + 4 requested
+        stage_write(p + 3);
+        stage_load(p + 4);
+        // (wave 3) unit tile 16's gate math for block p - 1, if that was this workgroup's: its recurrent accumulators were left in
+        // LDS by the h waves in the phase before, nobody reads image c in this phase
+        if (j == 3 && p >= 1 && ((p - 1) & 3) == c) {
+            const int t = (p - 1) >> 2;
             const char *gh = cx.smem + kQOffGh16 + (t & 1) * 3 * 1024 + lane * 16;
             f32x4 acc[3];
             acc[0] = *(const f32x4 *) gh;
             acc[1] = *(const f32x4 *) (gh + 1024);
             acc[2] = *(const f32x4 *) (gh + 2048);
-            q_flag_write(cx.flags + kFG16C * 4, t + 1);  // (behind the reads in this wave's DS queue)
-            q_stamp(cx, b16, 4);
             h16 = q_gates(acc, gi16[0], gi16[1], gi16[2], bh16r, bh16z, bh16n, h16);
             unsigned w0, w1;
             q_pack(h16, cx.even, w0, w1);
             q_image_write(cx, c, 16, w0, w1);
-            q_flag_write(cx.flags + kFH16 * 4, t + 1);
             q_publish(g, cx, t, c, 16, w0, w1);
-            q_stamp(cx, b16, 5);
-            ++t16;
-            spin = 0;
-            continue;
         }
-        // next block: staged, ring slot free, and (m = c) the previous step's gi16 consumed
-        const bool late = cx.lane5 < 4 ? v < b + 1 : (cx.lane5 == kFGC + 3 ? v < b + 1 - kQDG : false);
-        const bool tile16 = (b & 3) == c;
-        if (b < cx.NB && (!tile16 || t16 >= (b >> 2)) && __builtin_amdgcn_ballot_w64(late) == 0) {
-            q_stamp(cx, b, 1);
-            if (tile16)
-                do_block(b, std::true_type{});
-            else
-                do_block(b, std::false_type{});
-            q_stamp(cx, b, 3);
-            ++b;
-            spin = 0;
-            continue;
-        }
-        if (++spin > kQSpinLimit) {
-            q_abort(cx, 0x13000000u | (unsigned) (b & 0xffff) | ((unsigned) (t16 & 0xff) << 16));
-            return;
-        }
-        __builtin_amdgcn_s_sleep(1);
+        q_stamp(cx, p, 1);
+        if (p + 1 < cx.NB) project(p + 1);
+        q_stamp(cx, p, 2);
+        // the other workgroups' tiles of what h-block p + 1 reads (requested in the phase before), then the request for p + 2
+        file(p + 1);
+        q_stamp(cx, p, 3);
+        asm volatile("" ::: "memory");
+        request(p + 2);
+        q_barrier();
     }
-    ((f32x4 *) g.hstate_out)[((size_t) (cx.mt0 + c) * kUnitTiles + 16) * 64 + lane] = h16;
+    if (j == 3) ((f32x4 *) g.hstate_out)[((size_t) (cx.mt0 + c) * kUnitTiles + 16) * 64 + lane] = h16;
 }
 
 // ------------------------------------------------------------------------------------------------ h waves
 
 // 27 MFMAs of one block against the wave's register-resident W_hh tile; kW16: one gate of unit tile 16 as a fourth chain,
-// its weights read from LDS through a two-deep queue
+// its weights read from LDS through the same rolling queue
 template <bool kW16>
 __device__ __forceinline__ void q_h_mma(f32x4 (&acc)[3], f32x4 &a16, const bf16x8 *ha, const bf16x8 (&w)[27], const bf16x8 *w16,
                                         int lane) {
@@ -496,59 +404,40 @@ __device__ __forceinline__ void q_h_wave(const GruQuadArgs &g, const QCtx &cx, c
     f32x4 hreg[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) hreg[m] = ((const f32x4 *) g.hstate_in)[((size_t) (cx.mt0 + m) * kUnitTiles + u) * 64 + lane];
-
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the resident weights, bias and initial state are in (see q_x_wave)
-    unsigned w0p = 0, w1p = 0;  // block b - 1's tile, not yet in its image (readers may still have been at it)
-    for (int b = 0; b < cx.NB; ++b) {
-        const int t = b >> 2, m = b & 3;
-        q_stamp(cx, b, 0);
-        // ---- ONE wait per block: this block's pre-activations; every tile of h_{t-1} in the image (this workgroup's tiles of
-        // h-block b - 4, the remote ones filed by the x waves, tile 16); every h wave through with READING h-block b - 1's
-        // image, so that this wave's tile of that block can go in
-        {
-            const int need = cx.lane5 == kFGI + j ? b + 1
-                             : (cx.lane5 >= kFHL && cx.lane5 < kFHL + 4) ? b - 3
-                             : (cx.lane5 >= kFHG && cx.lane5 < kFHG + 4) ? b + 1
-                             : (cx.lane5 >= kFHM && cx.lane5 < kFHM + 4) ? b
-                             : (cx.lane5 == kFH16 && m == c) ? t
-                             : (cx.lane5 == kFG16C && m == c && j < 3) ? t - 1
-                                                                       : INT_MIN;
-            if (!q_wait(cx, need, 0x20000000u | (unsigned) (j << 24) | (unsigned) b, b)) return;
-        }
-        if (b > 0) {
-            q_image_write(cx, (b - 1) & 3, u, w0p, w1p);
-            q_flag_write(cx.flags + (kFHL + j) * 4, b);
-        }
-        q_stamp(cx, b, 1);
-        const frag_t *ha = (const frag_t *) (cx.smem + kQOffHs + m * kQHsBytes);  // holds h_{t-1} now
-        f32x4 acc[3], a16 = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned w0p = 0, w1p = 0;  // block p - 1's tile: into its image at the start of phase p, when nobody reads that image
+    q_barrier();                // (phase -1: the x waves compute block 0's pre-activations)
+    for (int p = 0; p <= cx.NB; ++p) {
+        q_stamp(cx, p, 0);
+        if (p >= 1) q_image_write(cx, (p - 1) & 3, u, w0p, w1p);
+        if (p < cx.NB) {
+            const int t = p >> 2, m = p & 3;
+            const frag_t *ha = (const frag_t *) (cx.smem + kQOffHs + m * kQHsBytes);  // holds h_{t-1} now
+            f32x4 acc[3], a16 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const bool with16 = (m == c) && (j < 3);
-        if (with16)
-            q_h_mma<true>(acc, a16, ha, w, w16, lane);
-        else
-            q_h_mma<false>(acc, a16, ha, w, w16, lane);
-        q_flag_write(cx.flags + (kFHM + j) * 4, b + 1);  // (behind this block's operand reads in the wave's DS queue)
-        q_stamp(cx, b, 2);
-        if (with16) {
-            *(f32x4 *) (cx.smem + kQOffGh16 + ((t & 1) * 3 + j) * 1024 + lane * 16) = a16;
-            q_flag_write(cx.flags + (kFGH16 + j) * 4, t + 1);
+            for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool with16 = (m == c) && (j < 3);
+            if (with16)
+                q_h_mma<true>(acc, a16, ha, w, w16, lane);
+            else
+                q_h_mma<false>(acc, a16, ha, w, w16, lane);
+            q_stamp(cx, p, 1);
+            if (with16) *(f32x4 *) (cx.smem + kQOffGh16 + ((t & 1) * 3 + j) * 1024 + lane * 16) = a16;
+            const char *ring = cx.smem + kQOffGi + (((p & 1) * 4 + j) * 3) * 512 + lane * 8;
+            const u32x2 pr = *(const u32x2 *) ring, pz = *(const u32x2 *) (ring + 512), pn = *(const u32x2 *) (ring + 1024);
+            // (m is a runtime value: select the register, do not index the array)
+            const f32x4 hprev = m == 0 ? hreg[0] : m == 1 ? hreg[1] : m == 2 ? hreg[2] : hreg[3];
+            const f32x4 hnew = q_gates(acc, pr, pz, pn, br, bz, bn, hprev);
+            if (m == 0) hreg[0] = hnew;
+            if (m == 1) hreg[1] = hnew;
+            if (m == 2) hreg[2] = hnew;
+            if (m == 3) hreg[3] = hnew;
+            q_stamp(cx, p, 2);
+            q_pack(hnew, cx.even, w0p, w1p);
+            q_publish(g, cx, t, m, u, w0p, w1p);
+            q_stamp(cx, p, 3);
         }
-        const char *ring = cx.smem + kQOffGi + ((j * kQDG + (b & (kQDG - 1))) * 3) * 512 + lane * 8;
-        const u32x2 pr = *(const u32x2 *) ring, pz = *(const u32x2 *) (ring + 512), pn = *(const u32x2 *) (ring + 1024);
-        q_flag_write(cx.flags + (kFGC + j) * 4, b + 1);  // (behind the three reads in this wave's DS queue)
-        // (m is a runtime value: select the register, do not index the array)
-        const f32x4 hprev = m == 0 ? hreg[0] : m == 1 ? hreg[1] : m == 2 ? hreg[2] : hreg[3];
-        const f32x4 hnew = q_gates(acc, pr, pz, pn, br, bz, bn, hprev);
-        if (m == 0) hreg[0] = hnew;
-        if (m == 1) hreg[1] = hnew;
-        if (m == 2) hreg[2] = hnew;
-        if (m == 3) hreg[3] = hnew;
-        q_stamp(cx, b, 3);
-        q_pack(hnew, cx.even, w0p, w1p);
-        q_publish(g, cx, t, m, u, w0p, w1p);
-        q_stamp(cx, b, 5);
+        q_barrier();
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m) ((f32x4 *) g.hstate_out)[((size_t) (cx.mt0 + m) * kUnitTiles + u) * 64 + lane] = hreg[m];
@@ -568,11 +457,8 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad_kernel(GruQuadArgs g
     QCtx cx;
     cx.smem = smem;
     cx.dbg = (g.dbg && bid == g.dbg_block) ? g.dbg + (size_t) wave * 4 * g.T * 8 : nullptr;
-    cx.flags = (unsigned) (uintptr_t) (smem + kQOffFlags);
-    cx.flags_lane = cx.flags + (lane & 31) * 4;
     cx.err = g.err;
     cx.lane = lane;
-    cx.lane5 = lane & 31;
     cx.colq = lane & 15;
     cx.c = (bid >> 3) & 3;
     cx.T = g.T;
@@ -592,30 +478,26 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad_kernel(GruQuadArgs g
     cx.mt0 = 4 * qq;
 
     // ---- prologue: unit tile 16's weights (LDS-resident for the whole launch), zeroed operand images (k-block 8's upper half
-    // stays zero for good), counters, initial h, block 0's x
+    // stays zero for good), initial h, x of blocks 0, 1, 2
     for (int i = wave; i < 3 * NBX; i += kQWaves)
         ((bf16x8 *) (smem + kQOffW16x))[i * 64 + lane] = ((const bf16x8 *) g.wih)[((size_t) 48 * NBX + i) * 64 + lane];
     for (int i = wave; i < 27; i += kQWaves)
         ((bf16x8 *) (smem + kQOffW16h))[i * 64 + lane] = ((const bf16x8 *) g.whh)[((size_t) 48 * 9 + i) * 64 + lane];
     for (int i = tid; i < 4 * kQHsBytes / 16; i += 64 * kQWaves) ((uint4 *) (smem + kQOffHs))[i] = uint4{0, 0, 0, 0};
-    if (tid < 32) ((int *) (smem + kQOffFlags))[tid] = (tid >= kFHG && tid < kFHG + 4) ? 4 : 0;
     __syncthreads();
     for (int idx = wave; idx < 4 * kUnitTiles; idx += kQWaves) {
         const int m = idx / kUnitTiles, u = idx % kUnitTiles;
         const f32x4 hv = ((const f32x4 *) g.hstate_in)[((size_t) (cx.mt0 + m) * kUnitTiles + u) * 64 + lane];
         unsigned w0, w1;
         q_pack(hv, cx.even, w0, w1);
-        char *img = smem + kQOffHs + m * kQHsBytes + q_tile_off(u) + cx.lane_off;  // h_{-1}
-        *(unsigned *) img = w0;
-        *(unsigned *) (img + 16) = w1;
+        q_image_write(cx, m, u, w0, w1);  // h_{-1}
     }
-    for (int i = wave; i < 2 * NBX; i += kQWaves) {  // blocks 0 and 1 (= m-tiles 0 and 1 of step 0; T = 1 has four blocks too)
+    for (int i = wave; i < 3 * NBX; i += kQWaves) {  // blocks 0, 1, 2 (= m-tiles 0, 1, 2 of step 0)
         const int blk = i / NBX, k = i % NBX;
         const bf16x8 *src = k < NB0 ? (const bf16x8 *) g.a0 + ((size_t) (cx.mt0 + blk) * NB0 + k) * 64
                                     : (const bf16x8 *) g.a1 + ((size_t) (cx.mt0 + blk) * 9 + (k - NB0)) * 64;
         ((bf16x8 *) (smem + kQOffXs))[i * 64 + lane] = src[lane];
     }
-    if (tid < 4) ((int *) (smem + kQOffFlags))[kFXW + tid] = 2;
     __syncthreads();
     if (wave < 4)
         q_x_wave<NB0>(g, cx, wave);
