@@ -43,7 +43,7 @@ def main():
         nxt = np.concatenate([s[1:, 0], s[-1:, 0]])
         d = [s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2], nxt - s[:, 3]]
         if w < 4:
-            print('x wave %d: stage(+tile-16 gates) %.0f  projection %.0f  file %.0f  request+barrier %.0f | re-polls per phase %.2f' % (
+            print('x wave %d: stage(+tile-16 gates) %.0f  file+request %.0f  projection %.0f  barrier %.0f | re-polls per phase %.2f' % (
                 (w,) + tuple(v[:-1].mean() for v in d) + ((s[:, 7].astype(np.int64) & 0xffff).mean(),)))
         else:
             print('h wave %d: image write+MFMA %.0f  gi+gates %.0f  pack+publish %.0f  barrier %.0f' % (
