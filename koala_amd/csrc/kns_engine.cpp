@@ -260,7 +260,10 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     dev_synth_seg_ = dev_int("KOALA_AMD_SYNTH_SEG", 0);
     dev_small_mt_ = dev_int("KOALA_AMD_SMALL_MT", 0);
     dev_steps_mt_ = dev_int("KOALA_AMD_STEPS_MT", 192);
-    use_quad_ = dev_env("KOALA_AMD_NO_QUAD") == nullptr;  // A/B arm: input GEMM + recurrent kernel per layer instead of the fused one
+    // A/B arm (developer build only, opt-in): GRU layers as ONE launch fused over CU quads (kns_gruq.hip).  Bit-identical to
+    // the two-kernel form and measured SLOWER at the bench shape (354 against 278 us per layer), so the
+    // product does not take it.
+    use_quad_ = dev_env("KOALA_AMD_QUAD") != nullptr;
     quad_nb0_max_ = dev_int("KOALA_AMD_QUAD_NB0MAX", 2);
     qdbg_block_ = dev_int("KOALA_AMD_QUAD_DBG", -1);
     // host-pointer calls are cut into sub-chunks of host_chunk_ frames (two staging slots = the Tmax-sized buffers)
@@ -358,8 +361,10 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     d_hseq_a_ = dalloc(M * nbh_ * 1024, true);
     d_hseq_b_ = dalloc(M * nbh_ * 1024, true);
     d_mask_ = (float *) dalloc(M * kMaskTiles * 1024, true);
-    d_xchg_ = dalloc(mtb * kQuadXchgBytesPerMtile, true);  // tags start at 0 = never valid
-    d_qerr_ = (unsigned *) dalloc(16, true);
+    if (use_quad_) {
+        d_xchg_ = dalloc(mtb * kQuadXchgBytesPerMtile, true);  // tags start at 0 = never valid
+        d_qerr_ = (unsigned *) dalloc(16, true);
+    }
     if (qdbg_block_ >= 0) d_qdbg_ = (unsigned long long *) dalloc((size_t) 8 * 4 * Tmax_ * 8 * 8, true);
     d_in_ = (int16_t *) dalloc((size_t) B_ * Tmax_ * kFrame * 2, true);
     d_out_ = (int16_t *) dalloc((size_t) B_ * Tmax_ * kFrame * 2, true);
@@ -668,7 +673,9 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         g.dbg_block = qdbg_block_;
         quad_used_ = true;
         tick(kClsGru);
+#ifdef KNS_DEV
         if (only < 0 || only == kClsGru) launch_gru_quad(g, stream_);
+#endif
         tock(kClsGru);
     };
 
@@ -686,13 +693,13 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
             for (int t = 0; t < T; ++t)
                 gru_small(nullptr, 0, d_hseq_a_, d.w_ih_b, d.b_ih_b, d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_, t);
         } else {
-            if (quad && nby <= quad_nb0_max_ && gru_quad_supported(prec_, mtb, nby)) {
+            if (quad && nby <= quad_nb0_max_ && mtb % 4 == 0 && prec_ == kBf16) {
                 gru_quad(yprev, nby, d_e_, d.w_ih_a, d.b_ih_a, d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_);
             } else {
                 gemm(kClsGemmIn, yprev, nby, d_e_, nbh_, d.w_ih_a, d.b_ih_a, d_gi_, kGateTiles, 3 * kHidden, kOutGi);
                 gru(d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_);
             }
-            if (quad && gru_quad_supported(prec_, mtb, 0)) {
+            if (quad && mtb % 4 == 0 && prec_ == kBf16) {
                 gru_quad(nullptr, 0, d_hseq_a_, d.w_ih_b, d.b_ih_b, d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_);
             } else {
                 gemm(kClsGemmIn, nullptr, 0, d_hseq_a_, nbh_, d.w_ih_b, d.b_ih_b, d_gi_, kGateTiles, 3 * kHidden, kOutGi);

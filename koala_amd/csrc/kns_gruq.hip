@@ -327,8 +327,8 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
 
     // ---- phase -1: blocks 0, 1, 2 of x are staged (kernel prologue); block 0's pre-activations, block 3's x on its way
     stage_load(3);
-    request(1);  // (nothing real before h-block 4; keeps the loop uniform)
     project(0);
+    request(1);  // (nothing real before h-block 4; keeps the loop uniform)
     q_barrier();
     for (int p = 0; p <= cx.NB; ++p) {
         q_stamp(cx, p, 0);
@@ -351,15 +351,16 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
             q_publish(g, cx, t, c, 16, w0, w1);
         }
         q_stamp(cx, p, 1);
-        // the other workgroups' tiles of what h-block p + 1 reads (requested at this point of the phase before), then the request
-        // for p + 2.  Before the projection: this is vector / LDS work while the partner h wave has the matrix pipe, and the
-        // projection's MFMAs then run under the partner's gate arithmetic.
+        if (p + 1 < cx.NB) project(p + 1);
+        q_stamp(cx, p, 2);
+        // the other workgroups' tiles of what h-block p + 1 reads (requested at the end of the phase before), then the request
+        // for p + 2.  (Filing BEFORE the projection -- vector / LDS work while the partner h wave has the matrix pipe -- measured
+        // slower, 405 against 354 us per layer: the requests then have had less than a phase to come back, and a global load
+        // takes about 1.5 us here.)
         file(p + 1);
+        q_stamp(cx, p, 3);
         asm volatile("" ::: "memory");
         request(p + 2);
-        q_stamp(cx, p, 2);
-        if (p + 1 < cx.NB) project(p + 1);
-        q_stamp(cx, p, 3);
         q_barrier();
     }
     if (j == 3) ((f32x4 *) g.hstate_out)[((size_t) (cx.mt0 + c) * kUnitTiles + 16) * 64 + lane] = h16;

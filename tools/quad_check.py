@@ -18,11 +18,11 @@ DEV = os.environ.get("QUAD_LIB") or koala_amd.developer_library_path()
 
 def make(B, T, quad, model):
     if quad:
-        os.environ.pop('KOALA_AMD_NO_QUAD', None)
+        os.environ['KOALA_AMD_QUAD'] = '1'
     else:
-        os.environ['KOALA_AMD_NO_QUAD'] = '1'
+        os.environ.pop('KOALA_AMD_QUAD', None)
     kb = koala_amd.create_batch('k', B, T, 'bf16', model_path=model, library_path=DEV)
-    os.environ.pop('KOALA_AMD_NO_QUAD', None)
+    os.environ.pop('KOALA_AMD_QUAD', None)
     return kb
 
 

@@ -5,6 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa
+os.environ['KOALA_AMD_QUAD'] = '1'
 import koala_amd
 from koala_amd import params
 from koala_amd.workload import synth_streams

@@ -8,6 +8,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402,F401
+os.environ['KOALA_AMD_QUAD'] = '1'
 import koala_amd  # noqa: E402
 from koala_amd import params  # noqa: E402
 from koala_amd.workload import synth_streams  # noqa: E402
@@ -43,7 +44,7 @@ def main():
         nxt = np.concatenate([s[1:, 0], s[-1:, 0]])
         d = [s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2], nxt - s[:, 3]]
         if w < 4:
-            print('x wave %d: stage(+tile-16 gates) %.0f  file+request %.0f  projection %.0f  barrier %.0f | re-polls per phase %.2f' % (
+            print('x wave %d: stage(+tile-16 gates) %.0f  projection %.0f  file %.0f  request+barrier %.0f | re-polls per phase %.2f' % (
                 (w,) + tuple(v[:-1].mean() for v in d) + ((s[:, 7].astype(np.int64) & 0xffff).mean(),)))
         else:
             print('h wave %d: image write+MFMA %.0f  gi+gates %.0f  pack+publish %.0f  barrier %.0f' % (
