@@ -51,15 +51,16 @@ LoadResult load_params(const char *path, Params *p, std::string *err) {
         *err = std::string("`") + path + "` is not a Koala (KNS1) model file.";
         return kLoadFormat;
     }
-    if (hdr[11] > 1) {  // oracle-only extension (oracle/kns_oracle.h): a front-end over several feature frames
+    p->front_taps = hdr[11] > 1 ? (int) hdr[11] : 1;  // KNS-v1.1: a front-end over the last N feature frames (header word 11)
+    if (p->front_taps > kMaxFrontTaps) {
         fclose(f);
-        *err = std::string("`") + path + "` has a front-end over " + std::to_string(hdr[11]) +
-               " feature frames: this engine implements KNS-v1 (one frame).";
+        *err = std::string("`") + path + "` has a front-end over " + std::to_string(hdr[11]) + " feature frames (at most " +
+               std::to_string(kMaxFrontTaps) + " are supported).";
         return kLoadFormat;
     }
     const size_t G3 = 3 * kHidden;
-    ok = read_vec(f, &p->mean, kBins) && read_vec(f, &p->scale, kBins) && read_vec(f, &p->w_in, (size_t) kBins * kHidden) &&
-         read_vec(f, &p->b_in, kHidden);
+    ok = read_vec(f, &p->mean, kBins) && read_vec(f, &p->scale, kBins) &&
+         read_vec(f, &p->w_in, (size_t) p->front_taps * kBins * kHidden) && read_vec(f, &p->b_in, kHidden);
     for (int s = 0; ok && s < kStages; ++s) {
         Params::Stage &st = p->st[s];
         p->head[s] = (int) hdr[6 + s];
@@ -87,6 +88,39 @@ LoadResult load_params(const char *path, Params *p, std::string *err) {
 // ------------------------------------------------------------------------------------------------ weight packing
 
 namespace {
+
+// the spec's logarithm (the device's kns_log in kns_device.hpp, operation for operation): the host needs
+// one value of it, the feature of a silent frame that a five-frame front-end sees before a stream began
+float host_kns_log(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    int e = (int) ((u >> 23) & 0xffu) - 126;
+    uint32_t mu = (u & 0x007fffffu) | 0x3f000000u;
+    float m;
+    memcpy(&m, &mu, 4);
+    if (m < 0.707106781186547524f) {
+        e -= 1;
+        m = (m + m) - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    float z = m * m;
+    float p = 7.0376836292e-2f;
+    p = fmaf(p, m, -1.1514610310e-1f);
+    p = fmaf(p, m, 1.1676998740e-1f);
+    p = fmaf(p, m, -1.2420140846e-1f);
+    p = fmaf(p, m, 1.4249322787e-1f);
+    p = fmaf(p, m, -1.6668057665e-1f);
+    p = fmaf(p, m, 2.0000714765e-1f);
+    p = fmaf(p, m, -2.4999993993e-1f);
+    p = fmaf(p, m, 3.3333331174e-1f);
+    float fe = (float) e;
+    float y = (p * m) * z;
+    y = fmaf(fe, -2.12194440e-4f, y);
+    y = fmaf(z, -0.5f, y);
+    float r = m + y;
+    return fmaf(fe, 0.693359375f, r);
+}
 
 struct Seg {
     int k0, klen;
@@ -237,6 +271,7 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     pi_ = prec_info(precision);
     nbf_ = ceil_div(kBins, pi_.kb);
     nbh_ = ceil_div(kHidden, pi_.kb);
+    taps_ = p.front_taps;
     if (hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking) != hipSuccess) {
         (void) hipGetLastError();
         *err = "Failed to create a HIP stream.";
@@ -303,7 +338,9 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     const int G3 = 3 * kHidden;
     {
         auto tiles = dense_tiles(kHidden, pi_.npb);
-        auto w = pack_b(p.w_in.data(), kHidden, {{0, kBins}}, tiles, precision);
+        std::vector<Seg> segs;  // one segment per stacked feature frame, oldest first: each padded to whole k-blocks like the features
+        for (int i = 0; i < p.front_taps; ++i) segs.push_back({i * kBins, kBins});
+        auto w = pack_b(p.w_in.data(), kHidden, segs, tiles, precision);
         auto b = pack_bias(p.b_in.data(), tiles);
         w_in_ = upload(w.data(), w.size());
         b_in_ = (float *) upload(b.data(), b.size() * 4);
@@ -354,7 +391,27 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     // ---- activation workspace
     const size_t M = mtb * (size_t) Tmax_;  // m-tiles per call
     d_spec_ = (float *) dalloc((size_t) Tmax_ * Bpad_ * 256 * 8, true);
-    d_feat_ = dalloc(M * nbf_ * 1024, true);
+    feat_frame_bytes_ = mtb * nbf_ * 1024;
+    d_feat_ = dalloc((M + (size_t) (taps_ - 1) * mtb) * nbf_ * 1024, true);  // [context frames | the call's frames]
+    if (taps_ > 1) {
+        d_fhist_ = dalloc((size_t) (taps_ - 1) * feat_frame_bytes_, true);
+        // one m-tile whose 16 rows are the feature of a silent frame, in the operand type and layout of `feat`
+        std::vector<uint8_t> tile((size_t) nbf_ * 1024, 0);
+        const float lg = host_kns_log(1e-10f);
+        for (int k = 0; k < kBins; ++k) {
+            const float v = (lg - p.mean[k]) * p.scale[k];
+            for (int r = 0; r < 16; ++r) {
+                const size_t off = (size_t) (k / pi_.kb) * 1024 + (size_t) pack_off(precision, r, k % pi_.kb) * pi_.esz;
+                if (precision == kBf16) {
+                    const uint16_t h = to_bf16(v);
+                    memcpy(tile.data() + off, &h, 2);
+                } else {
+                    memcpy(tile.data() + off, &v, 4);
+                }
+            }
+        }
+        d_silent_ = upload(tile.data(), tile.size());
+    }
     d_e_ = dalloc(M * nbh_ * 1024, true);
     for (int s = 0; s < kStages - 1; ++s) d_y_[s] = dalloc(M * nby_[s] * 1024, true);
     d_gi_ = dalloc(M * kGateTiles * 64 * pi_.gisz, true);
@@ -379,6 +436,13 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
         *oom = true;
         *err = "Failed to allocate pinned host memory.";
         return false;
+    }
+    if (taps_ > 1) {  // the front-end context of a fresh stream is silence, not zeros
+        std::string e2;
+        if (!reset(nullptr, &e2)) {
+            *err = e2;
+            return false;
+        }
     }
     if (hipStreamSynchronize(own_stream_) != hipSuccess) {
         *err = std::string("Device initialisation failed: ") + hipGetErrorString(hipGetLastError());
@@ -505,6 +569,10 @@ bool Engine::reset(const uint8_t *host_mask, std::string *err) {
     r.hstate = d_hstate_[0];
     r.hstate2 = d_hstate_[1];
     r.Bpad = Bpad_;
+    r.fhist = d_fhist_;
+    r.silent = d_silent_;
+    r.fhist_frames = taps_ - 1;
+    r.nbf = nbf_;
     r.mask = nullptr;
     if (host_mask) {
         std::vector<uint8_t> m((size_t) Bpad_, 0);
@@ -544,7 +612,10 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     an.mean = d_mean_;
     an.scale = d_scale_;
     an.spec = d_spec_;
-    an.feat = d_feat_;
+    char *feat_now = (char *) d_feat_ + (size_t) (taps_ - 1) * feat_frame_bytes_;  // behind the context frames
+    an.feat = feat_now;
+    if (taps_ > 1)  // [features of the last taps - 1 frames | this call's]: the front-end reads taps shifted views of it
+        (void) hipMemcpyAsync(d_feat_, d_fhist_, (size_t) (taps_ - 1) * feat_frame_bytes_, hipMemcpyDeviceToDevice, stream_);
     an.B = B_;
     an.Bpad = Bpad_;
     an.T = T;
@@ -572,8 +643,10 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     if (!in_place) hist_cur_ ^= 1;
 
     auto gemm = [&](int cls, const void *a0, int nb0, const void *a1, int nb1, const void *w, const float *bias,
-                    void *out, int ntiles, int n_valid, int kind) {
+                    void *out, int ntiles, int n_valid, int kind, int taps = 1) {
         GemmArgs g;
+        g.taps = taps;
+        g.tap_stride = feat_frame_bytes_;
         g.a0 = a0;
         g.a1 = a1;
         g.w = w;
@@ -680,7 +753,10 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     };
 
     // front-end: e = features . W_in + b_in
-    gemm(kClsGemmHead, nullptr, 0, d_feat_, nbf_, w_in_, b_in_, d_e_, nbh_ * pi_.npb, kHidden, kOutAPlain);
+    gemm(kClsGemmHead, nullptr, 0, d_feat_, nbf_, w_in_, b_in_, d_e_, nbh_ * pi_.npb, kHidden, kOutAPlain, taps_);
+    if (taps_ > 1)  // the last taps - 1 frames of [context | call] are the next call's context
+        (void) hipMemcpyAsync(d_fhist_, (char *) d_feat_ + (size_t) T * feat_frame_bytes_, (size_t) (taps_ - 1) * feat_frame_bytes_,
+                              hipMemcpyDeviceToDevice, stream_);
     for (int s = 0; s < kStages; ++s) {
         const StageDev &d = sd_[s];
         const void *yprev = s ? d_y_[s - 1] : nullptr;
@@ -975,7 +1051,8 @@ int64_t Engine::debug_read(int what, float *out, int64_t capacity, std::string *
         const int width = what == 0 ? kBins : kHidden, nb = what == 0 ? nbf_ : nbh_;
         n = (int64_t) T * B_ * width;
         if (n > capacity) return -2;
-        auto h = fetch(what == 0 ? d_feat_ : d_e_, (size_t) T * mtb * nb * 1024);
+        auto h = fetch(what == 0 ? (const char *) d_feat_ + (size_t) (taps_ - 1) * feat_frame_bytes_ : (const char *) d_e_,
+                       (size_t) T * mtb * nb * 1024);
         for (int t = 0; t < T; ++t)
             for (int b = 0; b < B_; ++b)
                 for (int k = 0; k < width; ++k)

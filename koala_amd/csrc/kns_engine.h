@@ -15,6 +15,7 @@ namespace kns {
 
 // host copy of a KNS1 parameter file (fp32, logical layout; see koala_amd/params.py)
 struct Params {
+    int front_taps = 1;  // feature frames the front-end sees (KNS-v1: 1; KNS-v1.1: up to 5, w_in then has front_taps * 257 rows, oldest frame first)
     int head[kStages];
     std::vector<float> mean, scale, w_in, b_in;
     struct Stage {
@@ -82,6 +83,11 @@ private:
     float *d_tail_[2] = {nullptr, nullptr}, *d_hstate_[2] = {nullptr, nullptr};
     int tail_cur_ = 0, hs_cur_ = 0;
     uint8_t *d_rmask_ = nullptr;
+    // front-end context (front_taps > 1): features of the last front_taps - 1 frames (A-packed, one "frame" = mtiles x nbf
+    // blocks), and one m-tile of the feature of a silent frame (what the context holds before a stream began)
+    int taps_ = 1;
+    void *d_fhist_ = nullptr, *d_silent_ = nullptr;
+    size_t feat_frame_bytes_ = 0;
 
     // activation workspace (fragment layouts)
     float *d_spec_ = nullptr, *d_mask_ = nullptr;

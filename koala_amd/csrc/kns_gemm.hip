@@ -7,10 +7,9 @@ namespace kns {
 
 // ------------------------------------------------------------------------------------------------ GEMM
 
-constexpr int kGemmMT = 4;  // m-tiles (of 16 stream-frames) per workgroup
 constexpr int kPF = 4;      // weight prefetch depth in k-blocks
 
-template <class P, int OUT>
+template <class P, int OUT, int kGemmMT>  // kGemmMT: m-tiles (of 16 stream-frames) per workgroup: as many as the A tile leaves room for in LDS
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename P::frag_t frag_t;
@@ -19,7 +18,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     constexpr int NU = kApack ? P::NPB : 1;  // n-tiles per unit of work
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nb = g.nb0 + g.nb1;
+    const int nb = g.nb0 + g.taps * g.nb1;
     const int mt0 = blockIdx.x * kGemmMT;
     const int mcount = min(kGemmMT, g.mtiles - mt0);
 
@@ -30,8 +29,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             const uint4 *src = (const uint4 *) g.a0 + (size_t) (mt0 + m) * g.nb0 * 64;
             for (int i = tid; i < g.nb0 * 64; i += 256) lds_a[m * nb * 64 + i] = src[i];
         }
-        const uint4 *src1 = (const uint4 *) g.a1 + (size_t) (mt0 + m) * g.nb1 * 64;
-        for (int i = tid; i < g.nb1 * 64; i += 256) lds_a[(m * nb + g.nb0) * 64 + i] = src1[i];
+        for (int tap = 0; tap < g.taps; ++tap) {
+            const uint4 *src1 = (const uint4 *) ((const char *) g.a1 + tap * g.tap_stride) + (size_t) (mt0 + m) * g.nb1 * 64;
+            for (int i = tid; i < g.nb1 * 64; i += 256) lds_a[(m * nb + g.nb0 + tap * g.nb1) * 64 + i] = src1[i];
+        }
     }
     for (int m = mcount; m < kGemmMT; ++m)
         for (int i = tid; i < nb * 64; i += 256) lds_a[m * nb * 64 + i] = uint4{0, 0, 0, 0};
@@ -494,28 +495,45 @@ __global__ __launch_bounds__(512, 2) void gemm_head_kernel(GemmArgs g) {
     }
 }
 
-template <class P>
-static void launch_gemm_p(const GemmArgs &a, hipStream_t s) {
-    const int nb = a.nb0 + a.nb1;
-    const int gx = ceil_div(a.mtiles, kGemmMT);
+template <class P, int MT>
+static void launch_gemm_mt(const GemmArgs &a, hipStream_t s) {
+    const int nb = a.nb0 + a.taps * a.nb1;
+    const int gx = ceil_div(a.mtiles, MT);
     const bool apack = a.out_kind == kOutAPlain || a.out_kind == kOutASigmoid;
     const int units = a.ntiles / (apack ? P::NPB : 1);
     // few stream-frames: split the n-tiles over more workgroups so the weight stream is spread over the CUs
     int gy = 1;
     if (gx < 256) gy = min(ceil_div(units, 4), max(1, 512 / gx));
-    size_t lds = (size_t) kGemmMT * nb * 1024 + 4 * kGemmMT * 1024;
+    const size_t lds = (size_t) MT * nb * 1024 + 4 * MT * 1024;
     dim3 grid(gx, gy);
+    auto go = [&](auto kernel) {
+        if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, a);
+    };
     switch (a.out_kind) {
-        case kOutGi: hipLaunchKernelGGL((gemm_kernel<P, kOutGi>), grid, dim3(256), lds, s, a); break;
-        case kOutMask: hipLaunchKernelGGL((gemm_kernel<P, kOutMask>), grid, dim3(256), lds, s, a); break;
-        case kOutAPlain: hipLaunchKernelGGL((gemm_kernel<P, kOutAPlain>), grid, dim3(256), lds, s, a); break;
-        default: hipLaunchKernelGGL((gemm_kernel<P, kOutASigmoid>), grid, dim3(256), lds, s, a); break;
+        case kOutGi: go(gemm_kernel<P, kOutGi, MT>); break;
+        case kOutMask: go(gemm_kernel<P, kOutMask, MT>); break;
+        case kOutAPlain: go(gemm_kernel<P, kOutAPlain, MT>); break;
+        default: go(gemm_kernel<P, kOutASigmoid, MT>); break;
     }
+}
+
+template <class P>
+static void launch_gemm_p(const GemmArgs &a, hipStream_t s) {
+    // m-tiles per workgroup: four where the A tile (K up to 11 k-blocks) fits LDS four times; the five-frame front-end
+    // (K = 45 / 85 k-blocks) leaves room for two / one
+    const int nb = a.nb0 + a.taps * a.nb1;
+    if (nb <= 30)
+        launch_gemm_mt<P, 4>(a, s);
+    else if (nb <= 60)
+        launch_gemm_mt<P, 2>(a, s);
+    else
+        launch_gemm_mt<P, 1>(a, s);
 }
 
 void launch_gemm(const GemmArgs &a, hipStream_t s) {
     const bool no_ws = (a.dev & kDevGemmGeneric) != 0;  // A/B switch (developer build only)
-    if (a.precision == kBf16 && a.out_kind == kOutGi && a.ntiles == kGateTiles && a.nb1 == PBF16::NBH && a.nb0 <= 2 &&
+    if (a.precision == kBf16 && a.out_kind == kOutGi && a.ntiles == kGateTiles && a.nb1 == PBF16::NBH && a.nb0 <= 2 && a.taps == 1 &&
         a.mtiles >= 256 && !no_ws) {
         // The weight-stationary kernel splits the m-tiles over 256 workgroup pairs: it takes the largest multiple of 256,
         // the remaining < 256 m-tiles (ragged stream counts) go through the generic kernel -- the same arithmetic, bit
@@ -549,7 +567,7 @@ void launch_gemm(const GemmArgs &a, hipStream_t s) {
         return;
     }
     const bool no_wsr = (a.dev & kDevGemmNoWsr) != 0;  // A/B switch (developer build only)
-    if (a.precision == kBf16 && a.nb0 == 0 && a.nb1 == PBF16::NBH && a.mtiles >= 512 && !no_wsr) {
+    if (a.precision == kBf16 && a.nb0 == 0 && a.nb1 == PBF16::NBH && a.taps == 1 && a.mtiles >= 512 && !no_wsr) {
         const dim3 grid(256), block(512);
         if (a.out_kind == kOutAPlain && a.ntiles <= 32) {
             hipLaunchKernelGGL((gemm_wsr_kernel<kOutAPlain, 2>), grid, block, 0, s, a);

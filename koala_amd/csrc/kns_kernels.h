@@ -72,6 +72,10 @@ struct GemmArgs {
     int n_valid;  // logical output width; columns >= n_valid are written as 0 in A-packed outputs
     int out_kind, precision;
     int dev = 0;  // DevVariant bits
+    // front-end over several stacked feature frames (KNS-v1.1): the a1 part of A is `taps` blocks of nb1 k-blocks, block i
+    // read from a1 + i * tap_stride bytes (the same feature buffer, one frame further on): K = nb0 + taps * nb1 k-blocks
+    int taps = 1;
+    size_t tap_stride = 0;
 };
 void launch_gemm(const GemmArgs &a, hipStream_t s);
 
@@ -143,6 +147,12 @@ struct ResetArgs {
     float *hstate2;
     const uint8_t *mask;  // [Bpad] device copy, or null for all
     int Bpad;
+    // front-end context (KNS-v1.1, front_taps > 1): the features of the last front_taps - 1 frames, A-packed
+    // [frames][mtiles][nbf] blocks; a reset stream's rows are set to the feature of a silent frame (`silent`: one A-packed
+    // m-tile [nbf] blocks whose 16 rows are all that feature)
+    void *fhist = nullptr;
+    const void *silent = nullptr;
+    int fhist_frames = 0, nbf = 0;
 };
 void launch_reset(const ResetArgs &a, hipStream_t s);
 

@@ -32,6 +32,7 @@ constexpr int kGateTiles = 3 * kUnitTiles;  // 51 n-tiles of a GRU matrix, order
 constexpr int kStages = 4;
 constexpr int kMaskTiles = 17;           // ceil(257 / 16)
 constexpr int kGruLayers = 2 * kStages;
+constexpr int kMaxFrontTaps = 5;         // KNS-v1.1: the front-end may see the last N <= 5 feature frames (the reference file has N = 5)
 
 enum Precision { kFp32 = 0, kBf16 = 1 };
 

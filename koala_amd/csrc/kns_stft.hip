@@ -377,6 +377,13 @@ __global__ void reset_kernel(ResetArgs g) {
         g.hstate[idx] = 0.0f;
         g.hstate2[idx] = 0.0f;
     }
+    // front-end context: this stream's row of every k-block of every remembered frame = the feature of a silent frame (in
+    // an A-packed block a row is the four 16-byte words of lanes row, row + 16, row + 32, row + 48)
+    for (int i = tid; i < g.fhist_frames * g.nbf * 4; i += 256) {
+        const int q = i & 3, kb = (i >> 2) % g.nbf, f = (i >> 2) / g.nbf;
+        const size_t word = (size_t) kb * 64 + row + 16 * q;
+        ((uint4 *) g.fhist)[((size_t) f * mtiles + mt) * g.nbf * 64 + word] = ((const uint4 *) g.silent)[word];
+    }
 }
 
 void launch_reset(const ResetArgs &a, hipStream_t s) {

@@ -35,7 +35,7 @@ MAGIC = b"KNS1\0\0\0\0"
 
 
 def tensor_order(front_taps: int = 1):
-    """`front_taps` > 1: oracle-only extension (a front-end over the last N feature frames, oldest first); the GPU engine
+    """`front_taps` > 1: KNS-v1.1 (a front-end over the last N <= 5 feature frames, oldest first, as in the reference's model file); the GPU engine
     and KNS-v1 proper have 1."""
     names = [("mean", (BINS,)), ("scale", (BINS,)), ("w_in", (front_taps * BINS, HIDDEN)), ("b_in", (HIDDEN,))]
     for s in range(STAGES):
@@ -80,11 +80,12 @@ def read_params(path: str) -> Dict[str, np.ndarray]:
     return out
 
 
-def make_random(seed: int = 1234, gain: float = 1.0) -> Dict[str, np.ndarray]:
-    """Seeded random parameter set: same dataflow and cost as any trained set; gates stay out of saturation."""
+def make_random(seed: int = 1234, gain: float = 1.0, front_taps: int = 1) -> Dict[str, np.ndarray]:
+    """Seeded random parameter set: same dataflow and cost as any trained set; gates stay out of saturation.
+    `front_taps` = 5 gives the front-end of the reference's model file (a linear layer over five stacked feature frames)."""
     rng = np.random.default_rng(seed)
     t = {}
-    for name, shape in tensor_order():
+    for name, shape in tensor_order(front_taps):
         if name == "mean":
             a = np.full(shape, -6.0) + 0.5 * rng.standard_normal(shape)
         elif name == "scale":
@@ -208,6 +209,8 @@ def ensure_params(path: str, kind: str = "random", seed: int = 1234, **kw) -> st
             write_params(path, make_random(seed, **kw))
         elif kind == "gate":
             write_params(path, make_gate(**kw))
+        elif kind == "random5":  # KNS-v1.1: the reference file's five-frame front-end, random weights
+            write_params(path, make_random(seed, front_taps=5, **kw))
         elif kind == "adaptive":
             write_params(path, make_adaptive_gate(**kw))
         elif kind == "unity":

@@ -33,7 +33,7 @@ def load_wav(name):
 
 def model_file(kind, seed=1234):
     from koala_amd import params
-    name = '%s_%d.kns' % (kind, seed) if kind == 'random' else '%s.kns' % kind
+    name = '%s_%d.kns' % (kind, seed) if kind.startswith('random') else '%s.kns' % kind
     if kind == 'gate':  # round 1's fixture-calibrated gate: its threshold is derived HERE from the reference's noise fixture
         return params.ensure_params(os.path.join(BUILD, name), kind, seed,
                                     threshold=params.noise_prior(load_wav('noise.wav')) + 2.15)
@@ -58,6 +58,12 @@ def noise_pcm():
 @pytest.fixture(scope='session')
 def random_model():
     return model_file('random', 1234)
+
+
+@pytest.fixture(scope='session')
+def random5_model():
+    """KNS-v1.1: random weights behind the reference file's five-frame front-end ([1285, 271])."""
+    return model_file('random5', 1234)
 
 
 @pytest.fixture(scope='session')

@@ -1,0 +1,119 @@
+"""
+KNS-v1.1 on the GPU: the front-end over FIVE stacked feature frames that the reference's model file has
+(lib/common/koala_params.pv, record at offset 1043: int32 {2, 2, 4, 1285, 271} + 1285 x 271 int8 -- SURVEY.md Appendix B,
+koala_amd/pv_import.py).  Four frames of feature history are per-stream state: they survive calls of any length, are
+set to "silence" by a reset (full or masked), and travel through the one-frame graph path.  Checked against the CPU oracle's
+front_taps mode through the C ABI, like every other parity test.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import koala_amd
+from conftest import synth_streams
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+BF16_TOL = int(os.environ.get('KOALA_TEST_BF16_TOL', '5'))
+
+
+def lsb(a, b):
+    return np.abs(a.astype(np.int64) - b.astype(np.int64))
+
+
+@pytest.mark.parametrize('precision,B,T,calls', [('fp32', 19, 3, 3), ('fp32', 1, 1, 7), ('bf16', 40, 8, 2), ('bf16', 272, 2, 4),
+                                                ('bf16', 4096, 4, 2)])
+def test_five_frame_front_end_matches_the_oracle(random5_model, precision, B, T, calls):
+    prec = oracle.PREC_BF16 if precision == 'bf16' else oracle.PREC_FP32
+    x = synth_streams(B, T * calls, seed=300 + B)
+    kb = koala_amd.create_batch('key', B, T, precision, model_path=random5_model)
+    ref = oracle.Oracle(random5_model, B, prec)
+    for c in range(calls):
+        xc = np.ascontiguousarray(x[:, c * T * 256:(c + 1) * T * 256])
+        d = lsb(kb.process(xc), ref.process(xc))
+        assert d.max() <= (BF16_TOL if precision == 'bf16' else 1), (c, int(d.max()))
+    kb.delete()
+
+
+def test_the_context_changes_the_output(random5_model, random_model):
+    """(guards against a front-end that silently ignores four of its five frames)"""
+    x = synth_streams(4, 6, seed=9)
+    kb = koala_amd.create_batch('key', 4, 6, 'fp32', model_path=random5_model)
+    y1 = kb.process(x)
+    kb.delete()
+    # the same weights with the four older taps zeroed behave differently
+    from koala_amd import params
+    t = params.read_params(random5_model)
+    t['w_in'][:4 * 257] = 0
+    p = os.path.join(os.path.dirname(random5_model), 'random5_last_tap_only.kns')
+    params.write_params(p, t)
+    kb = koala_amd.create_batch('key', 4, 6, 'fp32', model_path=p)
+    y2 = kb.process(x)
+    kb.delete()
+    assert lsb(y1, y2).max() > 50
+
+
+@pytest.mark.parametrize('precision,B,Tmax,calls', [('fp32', 21, 6, 20), ('bf16', 21, 6, 20), ('bf16', 4100, 3, 8)])
+def test_random_call_sequences_with_resets(random5_model, precision, B, Tmax, calls):
+    """The soak of tests/test_gpu_parity.py on the five-frame model: random chunk lengths (1 .. Tmax: shorter and longer than
+    the context), host and device pointers, masked and full resets -- the feature history must follow the oracle's."""
+    torch = pytest.importorskip('torch')
+    rng = np.random.default_rng(7)
+    prec = oracle.PREC_BF16 if precision == 'bf16' else oracle.PREC_FP32
+    tol = BF16_TOL if precision == 'bf16' else 1
+    kb = koala_amd.create_batch('key', B, Tmax, precision, model_path=random5_model)
+    ref = oracle.Oracle(random5_model, B, prec)
+    for call in range(calls):
+        T = int(rng.integers(1, Tmax + 1))
+        x = synth_streams(B, T, seed=2000 + call)
+        if call % 5 == 2:
+            mask = (rng.random(B) < 0.3).astype(np.uint8)
+            kb.reset(mask)
+            ref.reset(mask)
+        elif call == calls // 2:
+            kb.reset()
+            ref.reset()
+        if call % 3 == 0:
+            dx = torch.from_numpy(x).cuda()
+            dy = torch.zeros_like(dx)
+            torch.cuda.synchronize()
+            kb.process_device(T, dx.data_ptr(), dy.data_ptr())
+            kb.synchronize()
+            y = dy.cpu().numpy()
+        else:
+            y = kb.process(x)
+        want = ref.process(x)
+        assert lsb(y, want).max() <= tol, (call, T, int(lsb(y, want).max()))
+    kb.delete()
+
+
+def test_single_stream_abi_with_the_five_frame_model(random5_model, test_pcm):
+    """pv_koala_init / pv_koala_process (one frame per call, hipGraph replay) and pv_koala_reset on a KNS-v1.1 model."""
+    n = 40 * 256
+    k = koala_amd.create('key', model_path=random5_model, device='gpu:0')
+    ref = oracle.Oracle(random5_model, 1)
+    out = np.concatenate([np.array(k.process(test_pcm[i:i + 256]), np.int16) for i in range(0, n, 256)])
+    assert lsb(out, ref.process(test_pcm[:n])).max() <= 1
+    k.reset()
+    ref.reset()
+    out = np.concatenate([np.array(k.process(test_pcm[i:i + 256]), np.int16) for i in range(n, 2 * n, 256)])
+    assert lsb(out, ref.process(test_pcm[n:2 * n])).max() <= 1
+    k.delete()
+
+
+@pytest.mark.skipif(not os.path.exists('/root/reference/lib/common/koala_params.pv'), reason='reference checkout not present')
+def test_imported_reference_model_runs_on_the_gpu_like_on_the_oracle(tmp_path, test_pcm, noise_pcm):
+    """The reference's own parameter file under the default import hypothesis (koala_amd/pv_import.py: every record mapped, all
+    five front-end taps): GPU = oracle.  Says nothing about parity with the reference ENGINE (fixed-point conventions unknown,
+    profiles/r03_pv_import_search.json)."""
+    from koala_amd import params, pv_import
+    p = str(tmp_path / 'imported.kns')
+    params.write_params(p, pv_import.to_kns1(pv_import.read_pv('/root/reference/lib/common/koala_params.pv'),
+                                             pv_import.Hypothesis(front_tap=5)))
+    n = 60 * 256
+    x = np.stack([test_pcm[:n], noise_pcm[:n], (test_pcm[:n].astype(int) + noise_pcm[:n]).astype(np.int16)])
+    kb = koala_amd.create_batch('key', 3, 20, 'fp32', model_path=p)
+    y = np.concatenate([kb.process(np.ascontiguousarray(x[:, i:i + 20 * 256])) for i in range(0, n, 20 * 256)], axis=1)
+    kb.delete()
+    assert lsb(y, oracle.Oracle(p, 3).process(x)).max() <= 1

@@ -199,10 +199,10 @@ def test_blocked_gemm_equals_the_plain_statement(random_model, tmp_path):
 
 
 def test_front_end_context_extension(random_model, tmp_path):
-    """Oracle-only extension (kns_oracle.h: the front-end sees the last N feature frames, oldest first): with zero
-    weights on the older frames it is the one-frame model bit for bit; with the weight on the frame before, the
-    embedding tap is the one-frame model's embedding of that earlier frame; and the product library refuses such a
-    file by name (it implements KNS-v1 proper)."""
+    """KNS-v1.1 (kns_oracle.h: the front-end sees the last N <= 5 feature frames, oldest first; the GPU engine runs it too,
+    tests/test_gpu_front_taps.py): with zero weights on the older frames it is the one-frame model bit for bit; with the
+    weight on the frame before, the embedding tap is the one-frame model's embedding of that earlier frame; and a file
+    asking for more frames than the reference's five is refused by name."""
     import ctypes as C
     from koala_amd import params
     from koala_amd import _util
@@ -236,8 +236,12 @@ def test_front_end_context_extension(random_model, tmp_path):
     lib.pv_koala_init.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
     lib.pv_get_error_stack.argtypes = [C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.c_int32)]
     h = C.c_void_p()
-    assert lib.pv_koala_init(b'key', p5.encode(), b'best', C.byref(h)) == 2
+    raw = bytearray(open(p5, 'rb').read())
+    raw[8 + 11 * 4:8 + 12 * 4] = (6).to_bytes(4, 'little')  # header word 11: front-end taps
+    p6 = str(tmp_path / 'taps6.kns')
+    open(p6, 'wb').write(bytes(raw))
+    assert lib.pv_koala_init(b'key', p6.encode(), b'best', C.byref(h)) == 2
     ref, depth = C.POINTER(C.c_char_p)(), C.c_int32()
     lib.pv_get_error_stack(C.byref(ref), C.byref(depth))
-    assert b'front-end over 5 feature frames' in ref[0]
+    assert b'front-end over 6 feature frames' in ref[0]
     lib.pv_free_error_stack(ref)
