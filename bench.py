@@ -185,6 +185,7 @@ def machine_state():
 
 def extra_points(args, torch, np, koala_amd, model, kb, x, dx, dy, base, local_rank):
     """The other BASELINE operating points, on the same box in the same run (rank 0 of a single-GPU run)."""
+    from koala_amd import params
     from koala_amd.workload import synth_streams
     B, T = args.streams, args.frames
     out = {}
@@ -208,6 +209,22 @@ def extra_points(args, torch, np, koala_amd, model, kb, x, dx, dy, base, local_r
     dt = time_steps(lambda: kb.process_into(px, py), lambda: None, 4, 1)
     out['host_pinned'] = {'workload': '%d x %d frames per call, caller buffers page-locked (pv_koala_batch_host_alloc)' % (B, T),
                           'frames_per_s': round(B * T * 4 / dt, 1)}
+
+    # -- KNS-v1.1: the same batch with the reference model file's front-end topology (a linear layer over FIVE stacked feature
+    # frames, koala_params.pv record [1285, 271]: + 4 x 257 x 271 = 278 588 MAC per stream-frame, 3 992 914 in all)
+    m5 = params.ensure_params(os.path.join(ROOT, 'build', 'random5_1234.kns'), 'random5', 1234)
+    k5 = koala_amd.create_batch('bench', B, T, args.precision, model_path=m5, device=dev, library_path=args.library)
+    k5.set_stream(torch.cuda.current_stream().cuda_stream)
+    dt = time_steps(lambda: k5.process_device(T, dx.data_ptr(), dy.data_ptr()), sync, 100, 10)
+    k5.profile_enable(True)
+    for _ in range(10):
+        k5.process_device(T, dx.data_ptr(), dy.data_ptr())
+    p5 = k5.profile_read()
+    k5.delete()
+    out['front_taps5'] = {'workload': 'KNS-v1.1 (five-frame front-end, random weights), %d streams x %d frames per call, %s' % (B, T, args.precision),
+                          'frames_per_s': round(B * T * 100 / dt, 1), 'ms_per_call': round(dt / 100 * 1e3, 4),
+                          'mac_per_stream_frame': MAC_GEMM_IN + MAC_GRU + MAC_HEAD + 4 * 257 * H,
+                          'gemm_head_class_ms_per_call': round(p5['gemm_head']['ms'] / 10, 4)}
 
     # -- BASELINE configs[1]: 256 streams, fp32 mask network
     for T1 in (32, 1):

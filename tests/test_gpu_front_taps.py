@@ -102,15 +102,16 @@ def test_single_stream_abi_with_the_five_frame_model(random5_model, test_pcm):
     k.delete()
 
 
-@pytest.mark.skipif(not os.path.exists('/root/reference/lib/common/koala_params.pv'), reason='reference checkout not present')
-def test_imported_reference_model_runs_on_the_gpu_like_on_the_oracle(tmp_path, test_pcm, noise_pcm):
+IMPORTED = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'build', 'imported_pv_default.kns')
+
+
+@pytest.mark.skipif(not os.path.exists(IMPORTED), reason='build/imported_pv_default.kns not there: tests/test_pv_import.py writes it in '
+                    'the build container, where the reference checkout is')
+def test_imported_reference_model_runs_on_the_gpu_like_on_the_oracle(test_pcm, noise_pcm):
     """The reference's own parameter file under the default import hypothesis (koala_amd/pv_import.py: every record mapped, all
-    five front-end taps): GPU = oracle.  Says nothing about parity with the reference ENGINE (fixed-point conventions unknown,
-    profiles/r03_pv_import_search.json)."""
-    from koala_amd import params, pv_import
-    p = str(tmp_path / 'imported.kns')
-    params.write_params(p, pv_import.to_kns1(pv_import.read_pv('/root/reference/lib/common/koala_params.pv'),
-                                             pv_import.Hypothesis(front_tap=5)))
+    five front-end taps), converted in the build container: GPU = oracle.  Says nothing about parity with the reference ENGINE
+    (fixed-point conventions unknown, profiles/r03_pv_import_search.json)."""
+    p = IMPORTED
     n = 60 * 256
     x = np.stack([test_pcm[:n], noise_pcm[:n], (test_pcm[:n].astype(int) + noise_pcm[:n]).astype(np.int16)])
     kb = koala_amd.create_batch('key', 3, 20, 'fp32', model_path=p)

@@ -48,6 +48,12 @@ def test_import_maps_all_records_and_writes_a_loadable_kns1(tmp_path):
     from oracle import oracle
     out = oracle.Oracle(p, 1).process(np.zeros(256 * 4, np.int16))
     assert out.shape == (1024,)
+    # the full import (all five front-end taps) as a KNS-v1.1 file under build/ (git-ignored; it travels to the GPU box with the
+    # working tree), where tests/test_gpu_front_taps.py runs it on the GPU against the oracle
+    full = os.path.join(ROOT, 'build', 'imported_pv_default.kns')
+    os.makedirs(os.path.dirname(full), exist_ok=True)
+    params.write_params(full, pv_import.to_kns1(m, pv_import.Hypothesis(front_tap=5)))
+    assert params.read_params(full)['w_in'].shape == (5 * 257, 271)
 
 
 def test_hypothesis_search_is_recorded_as_measured(test_pcm, noise_pcm, tmp_path):
