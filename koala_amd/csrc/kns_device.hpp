@@ -376,6 +376,35 @@ __device__ __forceinline__ float mix_fma(float a, float b, unsigned x) {
     return d;
 #endif
 }
+// ---- the bf16 configuration's gate arithmetic, shared by every bf16 recurrent kernel.  The operands arrive PRE-SCALED (the
+// constants of the exponentials are folded into the packed weights and biases, kns_layout.h) and the recurrent accumulators
+// start from b_hh, so a hidden unit costs 9 plain vector operations and 6 transcendentals:
+//   r = 1 / (1 + 2^(gi_r + gh_r))   z = 1 / (1 + 2^(gi_z + gh_z))   n = 1 - 2 / (1 + 2^(fma(r, gh_n, gi_n)))   h' = fma(z, h - n, n)
+__device__ __forceinline__ float gate_rcp1p_exp2(float y) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y)); }
+// gi as packed fp16 pairs (element 2 p and 2 p + 1 of the C fragment in word p), gh as fp32 C fragments, h the previous state
+__device__ __forceinline__ f32x4 gate_block_bf16(const unsigned (&pr)[2], const unsigned (&pz)[2], const unsigned (&pn)[2],
+                                                 const f32x4 &ar, const f32x4 &az, const f32x4 &an, const f32x4 &hprev) {
+    f32x4 hnew;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float r0 = gate_rcp1p_exp2(mix_add<0>(pr[p], ar[2 * p])), r1 = gate_rcp1p_exp2(mix_add<1>(pr[p], ar[2 * p + 1]));
+        const float z0 = gate_rcp1p_exp2(mix_add<0>(pz[p], az[2 * p])), z1 = gate_rcp1p_exp2(mix_add<1>(pz[p], az[2 * p + 1]));
+        const float q0 = gate_rcp1p_exp2(mix_fma<0>(r0, an[2 * p], pn[p])), q1 = gate_rcp1p_exp2(mix_fma<1>(r1, an[2 * p + 1], pn[p]));
+        const float n0 = __builtin_fmaf(q0, -2.0f, 1.0f), n1 = __builtin_fmaf(q1, -2.0f, 1.0f);
+        hnew[2 * p] = __builtin_fmaf(z0, hprev[2 * p] - n0, n0);
+        hnew[2 * p + 1] = __builtin_fmaf(z1, hprev[2 * p + 1] - n1, n1);
+    }
+    return hnew;
+}
+// the same on one element with the pre-activations already converted to fp32 (exactly: fp16 -> fp32 is exact, and
+// fma(x, 1, t) = x + t)
+__device__ __forceinline__ float gate_elem_bf16(float xr, float xz, float xn, float ar, float az, float an, float hprev) {
+    const float r = gate_rcp1p_exp2(xr + ar), z = gate_rcp1p_exp2(xz + az);
+    const float q = gate_rcp1p_exp2(__builtin_fmaf(r, an, xn));
+    const float n = __builtin_fmaf(q, -2.0f, 1.0f);
+    return __builtin_fmaf(z, hprev - n, n);
+}
+
 __device__ __forceinline__ f32x2 fast_sigmoid2(f32x2 x) {
     f32x2 e = x * f32x2{-1.44269504088896341f, -1.44269504088896341f};
     e = f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + f32x2{1.0f, 1.0f};

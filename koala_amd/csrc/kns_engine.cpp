@@ -352,12 +352,23 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
         std::vector<Seg> segs_a;
         if (st.d_in) segs_a.push_back({0, st.d_in});
         segs_a.push_back({st.d_in, kHidden});
+        // bf16 configuration: the gates are evaluated through 2^x, so the constants of
+        // sigma(x) = 1 / (1 + 2^(-x log2 e)) and tanh(x) = 1 - 2 / (1 + 2^(2 x log2 e)) are folded into the r / z and n columns of
+        // W_ih, W_hh and both biases BEFORE they are rounded to the operand type (one fp32 multiplication each; the oracle's
+        // bf16 mode does the same): the recurrent kernels then add and exponentiate, nothing else
+        auto gate_scaled = [&](const std::vector<float> &v, size_t rows) {
+            std::vector<float> o(v);
+            if (precision != kBf16) return o;
+            for (size_t r = 0; r < rows; ++r)
+                for (int c = 0; c < G3; ++c) o[r * G3 + c] = v[r * G3 + c] * (c < 2 * kHidden ? kGateScaleRZ : kGateScaleN);
+            return o;
+        };
         auto pk = [&](const std::vector<float> &w, const std::vector<Seg> &segs) {
-            auto img = pack_b(w.data(), G3, segs, gt, precision);
+            auto img = pack_b(gate_scaled(w, w.size() / G3).data(), G3, segs, gt, precision);
             return upload(img.data(), img.size());
         };
         auto pb = [&](const std::vector<float> &b) {
-            auto img = pack_bias(b.data(), gt);
+            auto img = pack_bias(gate_scaled(b, 1).data(), gt);
             return (float *) upload(img.data(), img.size() * 4);
         };
         d.w_ih_a = pk(st.w_ih_a, segs_a);

@@ -58,9 +58,17 @@ __global__ __launch_bounds__(64 * W, W / 4) void gru_kernel(GruArgs g) {
                 typename P::gi_t gir = gi[(u * 3 + 0) * 64 + lane];
                 typename P::gi_t giz = gi[(u * 3 + 1) * 64 + lane];
                 typename P::gi_t gin = gi[(u * 3 + 2) * 64 + lane];
+                const float br = g.bhh[(u * 3 + 0) * 16 + colq];
+                const float bz = g.bhh[(u * 3 + 1) * 16 + colq];
+                const float bn = g.bhh[(u * 3 + 2) * 16 + colq];
                 f32x4 acc[3];
 #pragma unroll
                 for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (P::kPrec == kBf16) {  // bf16 configuration: the recurrent chains start from b_hh (kns_device.hpp, gate_block_bf16)
+                    acc[0] = f32x4{br, br, br, br};
+                    acc[1] = f32x4{bz, bz, bz, bz};
+                    acc[2] = f32x4{bn, bn, bn, bn};
+                }
                 // B fragments two k-blocks ahead of their MFMAs, rotated through registers (a rolled loop: unrolling all 51
                 // fp32 k-block/gate pairs makes hipcc materialise an address pair per load and spill)
                 const frag_t *wu = whh + (size_t) u * 3 * NBH * 64 + lane;
@@ -86,27 +94,12 @@ __global__ __launch_bounds__(64 * W, W / 4) void gru_kernel(GruArgs g) {
 #pragma unroll
                     for (int gt = 0; gt < 3; ++gt) acc[gt] = P::mma(ab, bc[gt], acc[gt]);
                 }
-                const float br = g.bhh[(u * 3 + 0) * 16 + colq];
-                const float bz = g.bhh[(u * 3 + 1) * 16 + colq];
-                const float bn = g.bhh[(u * 3 + 2) * 16 + colq];
                 f32x4 ir = P::from_gi(gir), iz = P::from_gi(giz), in = P::from_gi(gin);
                 const int k = u * 16 + colq;
                 elem_t *dst = (elem_t *) hbuf[cur ^ 1] + (k / P::KB) * 64 * P::EPL;
                 if (P::kPrec == kBf16) {  // the bf16 configuration's gate arithmetic, identical in every bf16 kernel
-                    const f32x2 vbr = {br, br}, vbz = {bz, bz}, vbn = {bn, bn};
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        const f32x2 ar = {acc[0][2 * p], acc[0][2 * p + 1]}, az = {acc[1][2 * p], acc[1][2 * p + 1]},
-                                    an = {acc[2][2 * p], acc[2][2 * p + 1]};
-                        const f32x2 xr = {ir[2 * p], ir[2 * p + 1]}, xz = {iz[2 * p], iz[2 * p + 1]}, xn = {in[2 * p], in[2 * p + 1]};
-                        const f32x2 r = fast_sigmoid2(xr + (ar + vbr));
-                        const f32x2 z = fast_sigmoid2(xz + (az + vbz));
-                        const f32x2 n = fast_tanh2(gate_fma2(r, an + vbn, xn));
-                        const f32x2 hp = {hreg[q][2 * p], hreg[q][2 * p + 1]};
-                        const f32x2 h = gate_fma2(z, hp - n, n);
-                        hreg[q][2 * p] = h[0];
-                        hreg[q][2 * p + 1] = h[1];
-                    }
+                    for (int i = 0; i < 4; ++i) hreg[q][i] = gate_elem_bf16(ir[i], iz[i], in[i], acc[0][i], acc[1][i], acc[2][i], hreg[q][i]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) dst[P::off(rowq + i, k % P::KB)] = P::cvt(hreg[q][i]);
                 } else {
@@ -173,6 +166,10 @@ __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
     const frag_t *a0 = (const frag_t *) g.a0 + (size_t) mt * g.nb0 * 64 + lane;
     const frag_t *a1 = (const frag_t *) g.a1 + (size_t) mt * NBH * 64 + lane;
     f32x4 acci = f32x4{0.f, 0.f, 0.f, 0.f}, acch = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (P::kPrec == kBf16) {  // bf16 configuration: this gate's recurrent chain starts from its b_hh
+        const float bh = g.bhh[(u * 3 + gt) * 16 + colq];
+        acch = f32x4{bh, bh, bh, bh};
+    }
     constexpr int kAhead = 8;
     for (int b0 = 0; b0 < nb; b0 += kAhead) {
         frag_t a[kAhead], w[kAhead];
@@ -216,21 +213,8 @@ __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
                 bn = g.bhh[(u * 3 + 2) * 16 + colq];
     f32x4 hnew;
     if (P::kPrec == kBf16) {
-        const f32x2 vbr = {br, br}, vbz = {bz, bz}, vbn = {bn, bn};
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const f32x2 ar = {gh[0][2 * p], gh[0][2 * p + 1]}, az = {gh[1][2 * p], gh[1][2 * p + 1]},
-                        an = {gh[2][2 * p], gh[2][2 * p + 1]};
-            const f32x2 xr = {gin[0][2 * p], gin[0][2 * p + 1]}, xz = {gin[1][2 * p], gin[1][2 * p + 1]},
-                        xn = {gin[2][2 * p], gin[2][2 * p + 1]};
-            const f32x2 r = fast_sigmoid2(xr + (ar + vbr));
-            const f32x2 z = fast_sigmoid2(xz + (az + vbz));
-            const f32x2 n = fast_tanh2(gate_fma2(r, an + vbn, xn));
-            const f32x2 hp = {hown[2 * p], hown[2 * p + 1]};
-            const f32x2 h = gate_fma2(z, hp - n, n);
-            hnew[2 * p] = h[0];
-            hnew[2 * p + 1] = h[1];
-        }
+        for (int i = 0; i < 4; ++i) hnew[i] = gate_elem_bf16(gin[0][i], gin[1][i], gin[2][i], gh[0][i], gh[1][i], gh[2][i], hown[i]);
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -410,59 +394,40 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
         const __amdgpu_buffer_rsrc_t gnext = make_rsrc(
             (const P::gi_t *) g.gi + ((size_t) (t + 1 < g.T ? t + 1 : t) * g.mtiles + mt) * kGateTiles * 64, kGateTiles * 512);
 
-        auto gates = [&](const int q, const int u, f32x4 (&acc)[3]) {
-#ifdef KNS_GATE_NO_MIX
-            const f32x4 ir = P::from_gi(gi[q][0]), iz = P::from_gi(gi[q][1]), in = P::from_gi(gi[q][2]);
-#else
-            // the fp16 pre-activations enter the gate arithmetic through v_fma_mix_f32 (an f16 operand of an f32 fma):
-            // x + t as fma(x, 1, t) and fma(r, q, x) round once, exactly like the add / fma on the converted value, so
-            // the results are the same bit for bit and twelve conversions per tile are gone
+        auto gates = [&](const int q, f32x4 (&acc)[3]) {
+            // the fp16 pre-activations enter the gate arithmetic through v_fma_mix_f32 (an f16 operand of an f32 fma): x + t as
+            // fma(x, 1, t) and fma(r, q, x) round once, exactly like the add / fma on the converted value
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            const u32x2 pr = __builtin_bit_cast(u32x2, gi[q][0]), pz = __builtin_bit_cast(u32x2, gi[q][1]),
-                        pn = __builtin_bit_cast(u32x2, gi[q][2]);
-#endif
+            const u32x2 vr = __builtin_bit_cast(u32x2, gi[q][0]), vz = __builtin_bit_cast(u32x2, gi[q][1]),
+                        vn = __builtin_bit_cast(u32x2, gi[q][2]);
+            const unsigned pr[2] = {vr[0], vr[1]}, pz[2] = {vz[0], vz[1]}, pn[2] = {vn[0], vn[1]};
+            const int u = q ? u1 : u0;
 #pragma unroll
             for (int gt = 0; gt < 3; ++gt) gi[q][gt] = buf_load_gi(gnext, lane8, (u * 3 + gt) * 512u);
-            const float br = lbias[(u * 3 + 0) * 16 + colq], bz = lbias[(u * 3 + 1) * 16 + colq],
-                        bn = lbias[(u * 3 + 2) * 16 + colq];
-            const f32x2 vbr = {br, br}, vbz = {bz, bz}, vbn = {bn, bn};
-            f32x4 hnew;
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const f32x2 ar = {acc[0][2 * p], acc[0][2 * p + 1]}, az = {acc[1][2 * p], acc[1][2 * p + 1]},
-                            an = {acc[2][2 * p], acc[2][2 * p + 1]};
-#ifdef KNS_GATE_NO_MIX
-                const f32x2 xr = {ir[2 * p], ir[2 * p + 1]}, xz = {iz[2 * p], iz[2 * p + 1]}, xn = {in[2 * p], in[2 * p + 1]};
-                const f32x2 r = fast_sigmoid2(xr + (ar + vbr));
-                const f32x2 z = fast_sigmoid2(xz + (az + vbz));
-                const f32x2 n = fast_tanh2(gate_fma2(r, an + vbn, xn));
-#else
-                const f32x2 tr = ar + vbr, tz = az + vbz, tn = an + vbn;
-                const f32x2 r = fast_sigmoid2(f32x2{mix_add<0>(pr[p], tr[0]), mix_add<1>(pr[p], tr[1])});
-                const f32x2 z = fast_sigmoid2(f32x2{mix_add<0>(pz[p], tz[0]), mix_add<1>(pz[p], tz[1])});
-                const f32x2 n = fast_tanh2(f32x2{mix_fma<0>(r[0], tn[0], pn[p]), mix_fma<1>(r[1], tn[1], pn[p])});
-#endif
-                const f32x2 hp = {hreg[q][2 * p], hreg[q][2 * p + 1]};
-                const f32x2 h = gate_fma2(z, hp - n, n);
-                hnew[2 * p] = h[0];
-                hnew[2 * p + 1] = h[1];
-            }
+            const f32x4 hnew = gate_block_bf16(pr, pz, pn, acc[0], acc[1], acc[2], hreg[q]);
             hreg[q] = hnew;
             put_h(hn, u, hnew);
+        };
+        // the recurrent chains start from b_hh (bf16 configuration: kns_device.hpp, gate_block_bf16)
+        auto acc_init = [&](f32x4 (&acc)[3], const int u) {
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt) {
+                const float b = lbias[(u * 3 + gt) * 16 + colq];
+                acc[gt] = f32x4{b, b, b, b};
+            }
         };
 
         KNS_STAMP(1);
         f32x4 acc[3];
-#pragma unroll
-        for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc_init(acc, u0);
         r8_tile_mma<27, 1, 27>(acc, ha, w0, wl16, lane);
         KNS_STAMP(2);
-        gates(0, u0, acc);
+        gates(0, acc);
         KNS_STAMP(3);
-#pragma unroll
-        for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc_init(acc, u1);
         if (c16) {  // waves 1, 2, 3 also carry one gate of unit tile 16 (k-blocks in order in one accumulator) through this loop
-            f32x4 a16 = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float b16 = lbias[(u2 * 3 + g16) * 16 + colq];
+            f32x4 a16 = f32x4{b16, b16, b16, b16};
             r8_tile_mma<kR8RegFrags1, R8C_Q, kR8RegFrags1, true>(acc, ha, w1, wl1w, lane, &a16, wl16 + g16 * 64 + lane);
             acc16[g16 * 64 + lane] = a16;
             // LDS operations of one wave complete in order: whoever sees the flag sees the accumulators
@@ -471,7 +436,7 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
             r8_tile_mma<kR8RegFrags1, 3, kR8RegFrags1>(acc, ha, w1, wl1w, lane);
         }
         KNS_STAMP(4);
-        gates(1, u1, acc);
+        gates(1, acc);
         KNS_STAMP(5);
         KNS_STAMP(6);
         {  // (requested by every wave, used by waves 0..3)
@@ -487,14 +452,7 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
                 const float ar = ((const float *) acc16)[(0 * 64 + lane) * 4 + e16];
                 const float az = ((const float *) acc16)[(1 * 64 + lane) * 4 + e16];
                 const float an = ((const float *) acc16)[(2 * 64 + lane) * 4 + e16];
-                const float br = lbias[(u2 * 3 + 0) * 16 + colq], bz = lbias[(u2 * 3 + 1) * 16 + colq],
-                            bn = lbias[(u2 * 3 + 2) * 16 + colq];
-                // same operations, element by element, as the packed gate math above
-                const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((xr + (ar + br)) * -1.44269504088896341f));
-                const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((xz + (az + bz)) * -1.44269504088896341f));
-                const float rr = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gate_fma1(r, an + bn, xn) * 2.88539008177792681f));
-                const float n = gate_fma1(rr, -2.0f, 1.0f);
-                h16 = gate_fma1(z, h16 - n, n);
+                h16 = gate_elem_bf16(xr, xz, xn, ar, az, an, h16);  // (the accumulators started from b_hh)
                 put_h16(hn, h16);
             }
         }

@@ -96,26 +96,12 @@ __device__ __forceinline__ int q_tile_off(int u) { return (u >> 1) * 1024 + (u &
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// the bf16 configuration's gate arithmetic -- operation for operation what gru_resident8_kernel does
-__device__ __forceinline__ f32x4 q_gates(const f32x4 (&acc)[3], u32x2 pr, u32x2 pz, u32x2 pn, float br, float bz, float bn,
-                                         const f32x4 &hprev) {
+// the bf16 configuration's gate arithmetic -- what every bf16 recurrent kernel does (kns_device.hpp); the accumulators start
+// from b_hh
+__device__ __forceinline__ f32x4 q_gates(const f32x4 (&acc)[3], u32x2 vr, u32x2 vz, u32x2 vn, const f32x4 &hprev) {
     if (KQ_ABL & 8) return acc[0] + acc[1] + acc[2] + hprev;
-    const f32x2 vbr = {br, br}, vbz = {bz, bz}, vbn = {bn, bn};
-    f32x4 hnew;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const f32x2 ar = {acc[0][2 * p], acc[0][2 * p + 1]}, az = {acc[1][2 * p], acc[1][2 * p + 1]},
-                    an = {acc[2][2 * p], acc[2][2 * p + 1]};
-        const f32x2 tr = ar + vbr, tz = az + vbz, tn = an + vbn;
-        const f32x2 r = fast_sigmoid2(f32x2{mix_add<0>(pr[p], tr[0]), mix_add<1>(pr[p], tr[1])});
-        const f32x2 z = fast_sigmoid2(f32x2{mix_add<0>(pz[p], tz[0]), mix_add<1>(pz[p], tz[1])});
-        const f32x2 n = fast_tanh2(f32x2{mix_fma<0>(r[0], tn[0], pn[p]), mix_fma<1>(r[1], tn[1], pn[p])});
-        const f32x2 hp = {hprev[2 * p], hprev[2 * p + 1]};
-        const f32x2 h = gate_fma2(z, hp - n, n);
-        hnew[2 * p] = h[0];
-        hnew[2 * p + 1] = h[1];
-    }
-    return hnew;
+    const unsigned pr[2] = {vr[0], vr[1]}, pz[2] = {vz[0], vz[1]}, pn[2] = {vn[0], vn[1]};
+    return gate_block_bf16(pr, pz, pn, acc[0], acc[1], acc[2], hprev);
 }
 
 // h_t of unit tile u, m-tile (local) m, as this lane's two packed operand words: to the other workgroups as granules and to the
@@ -222,8 +208,6 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
     // (wave 3) unit tile 16: biases, fp32 state of m-tile c
     const float b16r = g.bih[(16 * 3 + 0) * 16 + cx.colq], b16z = g.bih[(16 * 3 + 1) * 16 + cx.colq],
                 b16n = g.bih[(16 * 3 + 2) * 16 + cx.colq];
-    const float bh16r = g.bhh[(16 * 3 + 0) * 16 + cx.colq], bh16z = g.bhh[(16 * 3 + 1) * 16 + cx.colq],
-                bh16n = g.bhh[(16 * 3 + 2) * 16 + cx.colq];
     f32x4 h16 = ((const f32x4 *) g.hstate_in)[((size_t) (cx.mt0 + c) * kUnitTiles + 16) * 64 + lane];
     // The resident weights have arrived before the loop is entered -- said explicitly: hipcc's wait-count pass otherwise merges
     // "still in flight" from the loop's entry edge into the loop header and makes every phase's MFMAs wait for the
@@ -344,7 +328,7 @@ __device__ __forceinline__ void q_x_wave(const GruQuadArgs &g, const QCtx &cx, c
             acc[0] = *(const f32x4 *) gh;
             acc[1] = *(const f32x4 *) (gh + 1024);
             acc[2] = *(const f32x4 *) (gh + 2048);
-            h16 = q_gates(acc, gi16[0], gi16[1], gi16[2], bh16r, bh16z, bh16n, h16);
+            h16 = q_gates(acc, gi16[0], gi16[1], gi16[2], h16);
             unsigned w0, w1;
             q_pack(h16, cx.even, w0, w1);
             q_image_write(cx, c, 16, w0, w1);
@@ -404,6 +388,7 @@ __device__ __forceinline__ void q_h_wave(const GruQuadArgs &g, const QCtx &cx, c
     for (int i = 0; i < 27; ++i) w[i] = whh[((size_t) (u * 3 + i % 3) * 9 + i / 3) * 64 + lane];
     const frag_t *w16 = (const frag_t *) (cx.smem + kQOffW16h) + (j < 3 ? j : 0) * 9 * 64;  // gate j of unit tile 16
     const float br = g.bhh[(u * 3 + 0) * 16 + cx.colq], bz = g.bhh[(u * 3 + 1) * 16 + cx.colq], bn = g.bhh[(u * 3 + 2) * 16 + cx.colq];
+    const float b16 = g.bhh[(16 * 3 + (j < 3 ? j : 0)) * 16 + cx.colq];  // gate j of unit tile 16
     f32x4 hreg[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) hreg[m] = ((const f32x4 *) g.hstate_in)[((size_t) (cx.mt0 + m) * kUnitTiles + u) * 64 + lane];
@@ -416,9 +401,10 @@ __device__ __forceinline__ void q_h_wave(const GruQuadArgs &g, const QCtx &cx, c
         if (p < cx.NB) {
             const int t = p >> 2, m = p & 3;
             const frag_t *ha = (const frag_t *) (cx.smem + kQOffHs + m * kQHsBytes);  // holds h_{t-1} now
-            f32x4 acc[3], a16 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 acc[3], a16 = f32x4{b16, b16, b16, b16};  // the recurrent chains start from b_hh
+            acc[0] = f32x4{br, br, br, br};
+            acc[1] = f32x4{bz, bz, bz, bz};
+            acc[2] = f32x4{bn, bn, bn, bn};
             const bool with16 = (m == c) && (j < 3);
             if (with16)
                 q_h_mma<true>(acc, a16, ha, w, w16, lane);
@@ -430,7 +416,7 @@ __device__ __forceinline__ void q_h_wave(const GruQuadArgs &g, const QCtx &cx, c
             const u32x2 pr = *(const u32x2 *) ring, pz = *(const u32x2 *) (ring + 512), pn = *(const u32x2 *) (ring + 1024);
             // (m is a runtime value: select the register, do not index the array)
             const f32x4 hprev = m == 0 ? hreg[0] : m == 1 ? hreg[1] : m == 2 ? hreg[2] : hreg[3];
-            const f32x4 hnew = q_gates(acc, pr, pz, pn, br, bz, bn, hprev);
+            const f32x4 hnew = q_gates(acc, pr, pz, pn, hprev);
             if (m == 0) hreg[0] = hnew;
             if (m == 1) hreg[1] = hnew;
             if (m == 2) hreg[2] = hnew;

@@ -32,6 +32,9 @@ constexpr int kGateTiles = 3 * kUnitTiles;  // 51 n-tiles of a GRU matrix, order
 constexpr int kStages = 4;
 constexpr int kMaskTiles = 17;           // ceil(257 / 16)
 constexpr int kGruLayers = 2 * kStages;
+// bf16 configuration: constants folded into the GRU weights and biases at pack time (r and z columns; n columns)
+constexpr float kGateScaleRZ = -1.44269504088896341f;  // -log2(e)
+constexpr float kGateScaleN = 2.88539008177792681f;    // 2 log2(e)
 constexpr int kMaxFrontTaps = 5;         // KNS-v1.1: the front-end may see the last N <= 5 feature frames (the reference file has N = 5)
 
 enum Precision { kFp32 = 0, kBf16 = 1 };

@@ -144,6 +144,17 @@ static void round_weights(float *w, size_t n) {
     for (size_t i = 0; i < n; ++i) w[i] = kns_round_bf16(w[i]);
 }
 
+/* bf16 mode: the gates are evaluated through 2^x,
+ *   sigma(x) = 1 / (1 + 2^(-x log2 e)),  tanh(x) = 1 - 2 / (1 + 2^(2 x log2 e)),
+ * and the constants are folded into the r / z and n columns of W_ih, W_hh and both biases -- one fp32 multiplication each,
+ * BEFORE the weights are rounded to bf16 -- exactly as the engine packs them (kns_engine.cpp, gate_scaled). */
+#define KNS_GATE_SCALE_RZ (-1.44269504088896341f)
+#define KNS_GATE_SCALE_N 2.88539008177792681f
+static void scale_gates(float *w, size_t rows) {
+    for (size_t r = 0; r < rows; ++r)
+        for (int c = 0; c < KNS_G3; ++c) w[r * KNS_G3 + c] = w[r * KNS_G3 + c] * (c < 2 * KNS_H ? KNS_GATE_SCALE_RZ : KNS_GATE_SCALE_N);
+}
+
 int kns_params_load(const char *path, int precision, kns_params_t **out) {
     FILE *f = fopen(path, "rb");
     if (!f) return -1;
@@ -190,6 +201,11 @@ int kns_params_load(const char *path, int precision, kns_params_t **out) {
         if ((is_weight) && bf) round_weights(q, (size_t) (n)); \
         q += (size_t) (n);                                   \
     } while (0)
+#define TAKE_GRU(ptr, rows, is_weight)                                   \
+    do {                                                                 \
+        if (bf) scale_gates(q, (size_t) (rows));                         \
+        TAKE(ptr, (size_t) (rows) * KNS_G3, is_weight);                  \
+    } while (0)
     TAKE(p->mean, KNS_BINS, 0);
     TAKE(p->scale, KNS_BINS, 0);
     TAKE(p->w_in, p->front_taps * KNS_BINS * KNS_H, 1);
@@ -198,17 +214,18 @@ int kns_params_load(const char *path, int precision, kns_params_t **out) {
         kns_stage_t *st = &p->st[s];
         st->d_in = s ? p->head[s - 1] : 0;
         st->d_out = p->head[s];
-        TAKE(st->w_ih_a, (st->d_in + KNS_H) * KNS_G3, 1);
-        TAKE(st->b_ih_a, KNS_G3, 0);
-        TAKE(st->w_hh_a, KNS_H * KNS_G3, 1);
-        TAKE(st->b_hh_a, KNS_G3, 0);
-        TAKE(st->w_ih_b, KNS_H * KNS_G3, 1);
-        TAKE(st->b_ih_b, KNS_G3, 0);
-        TAKE(st->w_hh_b, KNS_H * KNS_G3, 1);
-        TAKE(st->b_hh_b, KNS_G3, 0);
+        TAKE_GRU(st->w_ih_a, st->d_in + KNS_H, 1);
+        TAKE_GRU(st->b_ih_a, 1, 0);
+        TAKE_GRU(st->w_hh_a, KNS_H, 1);
+        TAKE_GRU(st->b_hh_a, 1, 0);
+        TAKE_GRU(st->w_ih_b, KNS_H, 1);
+        TAKE_GRU(st->b_ih_b, 1, 0);
+        TAKE_GRU(st->w_hh_b, KNS_H, 1);
+        TAKE_GRU(st->b_hh_b, 1, 0);
         TAKE(st->w_head, KNS_H * st->d_out, 1);
         TAKE(st->b_head, st->d_out, 0);
     }
+#undef TAKE_GRU
 #undef TAKE
     const double pi = 3.14159265358979323846;
     for (int n = 0; n < KNS_NFFT; ++n) p->window[n] = (float) sin(pi * (double) n / KNS_NFFT);
@@ -330,8 +347,13 @@ struct kns_oracle {
  * This is the plain statement of the arithmetic; gemm_block() below computes the same chains, bit for bit, with the
  * loops blocked for registers and caches (selected unless KNS_ORACLE_SIMPLE_GEMM is set in the environment). */
 static void gemm_block_simple(int nb, const float *x, int ldx, int K, const float *w, int N, const float *bias, float *acc,
-                              int lda, int round_x) {
-    for (int s = 0; s < nb; ++s) memset(acc + (size_t) s * lda, 0, sizeof(float) * (size_t) N);
+                              int lda, int round_x, int bias_first) {
+    for (int s = 0; s < nb; ++s) {
+        if (bias_first)
+            memcpy(acc + (size_t) s * lda, bias, sizeof(float) * (size_t) N);
+        else
+            memset(acc + (size_t) s * lda, 0, sizeof(float) * (size_t) N);
+    }
     for (int k = 0; k < K; ++k) {
         const float *wr = w + (size_t) k * N;
         for (int s = 0; s < nb; ++s) {
@@ -341,6 +363,7 @@ static void gemm_block_simple(int nb, const float *x, int ldx, int K, const floa
             for (int n = 0; n < N; ++n) a[n] = fmaf(xv, wr[n], a[n]);
         }
     }
+    if (bias_first) return; /* (the chains started from the bias) */
     for (int s = 0; s < nb; ++s) {
         float *a = acc + (size_t) s * lda;
         for (int n = 0; n < N; ++n) a[n] = a[n] + bias[n];
@@ -350,12 +373,16 @@ static void gemm_block_simple(int nb, const float *x, int ldx, int K, const floa
 /* Register-blocked form: R (up to 6) stream rows x 16 columns of accumulators live in 2R AVX registers while k runs over
  * the whole chain (one IEEE fma per lane and k step = fmaf), and a 16-column weight panel (K x 64 B) is reused from cache
  * by every row group of the block.  Each (s, n) is still its own k-ascending chain from 0 with the bias added last, so
- * the result is identical to gemm_block_simple; only the order in which independent chains are advanced differs. */
+ * the result is identical to gemm_block_simple; only the order in which independent chains are advanced differs.
+ * bias_first: the chains start from the bias instead of having it added at the end (the recurrent GEMMs of the bf16 mode). */
 #define KNS_PANEL_KERNEL(R)                                                                                             \
     static void panel16_r##R(const float *x, int ldx, int K, const float *w, int N, const float *bias, float *acc,     \
-                             int lda) {                                                                                 \
+                             int lda, int bias_first) {                                                                 \
         __m256 a[R][2];                                                                                                 \
-        for (int r = 0; r < R; ++r) a[r][0] = a[r][1] = _mm256_setzero_ps();                                            \
+        for (int r = 0; r < R; ++r) {                                                                                   \
+            a[r][0] = bias_first ? _mm256_loadu_ps(bias) : _mm256_setzero_ps();                                         \
+            a[r][1] = bias_first ? _mm256_loadu_ps(bias + 8) : _mm256_setzero_ps();                                     \
+        }                                                                                                               \
         for (int k = 0; k < K; ++k) {                                                                                   \
             const float *wr = w + (size_t) k * N;                                                                       \
             const __m256 w0 = _mm256_loadu_ps(wr), w1 = _mm256_loadu_ps(wr + 8);                                        \
@@ -366,8 +393,8 @@ static void gemm_block_simple(int nb, const float *x, int ldx, int K, const floa
             }                                                                                                           \
         }                                                                                                               \
         for (int r = 0; r < R; ++r) {                                                                                   \
-            _mm256_storeu_ps(acc + (size_t) r * lda, _mm256_add_ps(a[r][0], _mm256_loadu_ps(bias)));                    \
-            _mm256_storeu_ps(acc + (size_t) r * lda + 8, _mm256_add_ps(a[r][1], _mm256_loadu_ps(bias + 8)));            \
+            _mm256_storeu_ps(acc + (size_t) r * lda, bias_first ? a[r][0] : _mm256_add_ps(a[r][0], _mm256_loadu_ps(bias)));         \
+            _mm256_storeu_ps(acc + (size_t) r * lda + 8, bias_first ? a[r][1] : _mm256_add_ps(a[r][1], _mm256_loadu_ps(bias + 8))); \
         }                                                                                                               \
     }
 KNS_PANEL_KERNEL(1)
@@ -379,11 +406,11 @@ KNS_PANEL_KERNEL(6)
 
 static int g_simple_gemm = -1;
 
-static void gemm_block(int nb, const float *x, int ldx, int K, const float *w, int N, const float *bias, float *acc,
-                       int lda, int round_x) {
+static void gemm_block_b(int nb, const float *x, int ldx, int K, const float *w, int N, const float *bias, float *acc,
+                         int lda, int round_x, int bias_first) {
     if (g_simple_gemm < 0) g_simple_gemm = getenv("KNS_ORACLE_SIMPLE_GEMM") != NULL;
     if (g_simple_gemm) {
-        gemm_block_simple(nb, x, ldx, K, w, N, bias, acc, lda, round_x);
+        gemm_block_simple(nb, x, ldx, K, w, N, bias, acc, lda, round_x, bias_first);
         return;
     }
     float *xr = NULL;
@@ -394,25 +421,30 @@ static void gemm_block(int nb, const float *x, int ldx, int K, const float *w, i
         x = xr;
         ldx = K;
     }
-    typedef void (*panel_fn)(const float *, int, int, const float *, int, const float *, float *, int);
+    typedef void (*panel_fn)(const float *, int, int, const float *, int, const float *, float *, int, int);
     static const panel_fn kernels[7] = {NULL, panel16_r1, panel16_r2, panel16_r3, panel16_r4, panel16_r5, panel16_r6};
     const int n32 = N & ~15;
     for (int n0 = 0; n0 < n32; n0 += 16)
         for (int s = 0; s < nb; s += 6) {
             const int r = nb - s < 6 ? nb - s : 6;
-            kernels[r](x + (size_t) s * ldx, ldx, K, w + n0, N, bias + n0, acc + (size_t) s * lda + n0, lda);
+            kernels[r](x + (size_t) s * ldx, ldx, K, w + n0, N, bias + n0, acc + (size_t) s * lda + n0, lda, bias_first);
         }
     /* remaining columns (N mod 16; the narrowest heads entirely): the same chains, column by column */
     for (int s = 0; s < nb && n32 < N; ++s) {
         const float *xs = x + (size_t) s * ldx;
         float *a = acc + (size_t) s * lda;
         for (int n = n32; n < N; ++n) {
-            float v = 0.0f;
+            float v = bias_first ? bias[n] : 0.0f;
             for (int k = 0; k < K; ++k) v = fmaf(xs[k], w[(size_t) k * N + n], v);
-            a[n] = v + bias[n];
+            a[n] = bias_first ? v : v + bias[n];
         }
     }
     free(xr);
+}
+
+static void gemm_block(int nb, const float *x, int ldx, int K, const float *w, int N, const float *bias, float *acc,
+                       int lda, int round_x) {
+    gemm_block_b(nb, x, ldx, K, w, N, bias, acc, lda, round_x, 0);
 }
 
 /* one GRU layer step for a block of streams:  x [nb][K] -> h (in/out) [nb] pointers */
@@ -420,15 +452,27 @@ static void gru_block(int nb, const float *x, int ldx, int K, const float *w_ih,
                       const float *b_hh, float **h, int bf, float *gi, float *gh, float *hx) {
     gemm_block(nb, x, ldx, K, w_ih, KNS_G3, b_ih, gi, KNS_G3, bf);
     for (int s = 0; s < nb; ++s) memcpy(hx + (size_t) s * KNS_H, h[s], sizeof(float) * KNS_H);
-    gemm_block(nb, hx, KNS_H, KNS_H, w_hh, KNS_G3, b_hh, gh, KNS_G3, bf);
+    gemm_block_b(nb, hx, KNS_H, KNS_H, w_hh, KNS_G3, b_hh, gh, KNS_G3, bf, bf /* bf16 mode: chains start from b_hh */);
     for (int s = 0; s < nb; ++s) {
         float *gis = gi + (size_t) s * KNS_G3, *ghs = gh + (size_t) s * KNS_G3;
         for (int j = 0; j < KNS_H; ++j) {
             float ir = gis[j], iz = gis[KNS_H + j], in = gis[2 * KNS_H + j];
             if (bf) {
+                /* everything below lives in the pre-scaled domain (weights and biases carry -log2 e / 2 log2 e, scale_gates):
+                 *   r = 1 / (1 + 2^(gi_r + gh_r))   z likewise   n = 1 - 2 / (1 + 2^(fma(r, gh_n, gi_n)))   h' = fma(z, h - n, n)
+                 * -- the GPU's gate_block_bf16 (kns_device.hpp) with its hardware 2^x and reciprocal replaced by the spec's
+                 * polynomial exponential and an IEEE division */
                 ir = kns_round_fp16(ir);
                 iz = kns_round_fp16(iz);
                 in = kns_round_fp16(in);
+                const float ln2 = 0.693147180559945309f;
+                float r = 1.0f / (1.0f + kns_exp((ir + ghs[j]) * ln2));
+                float z = 1.0f / (1.0f + kns_exp((iz + ghs[KNS_H + j]) * ln2));
+                float q = 1.0f / (1.0f + kns_exp(fmaf(r, ghs[2 * KNS_H + j], in) * ln2));
+                float n = fmaf(q, -2.0f, 1.0f);
+                float hp = h[s][j];
+                h[s][j] = fmaf(z, hp - n, n);
+                continue;
             }
             float r = kns_sigmoid(ir + ghs[j]);
             float z = kns_sigmoid(iz + ghs[KNS_H + j]);
