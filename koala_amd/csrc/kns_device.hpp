@@ -368,11 +368,14 @@ __device__ __forceinline__ float mix_fma(float a, float b, unsigned x) {
 #ifdef KNS_GATE_UNFUSED
     return a * b + (float) __builtin_bit_cast(_Float16, (unsigned short) (HI ? x >> 16 : x));
 #else
+    // `a` is usually the result of a transcendental (v_rcp_f32): gfx950 wants a wait state between a transcendental and a
+    // plain VALU reader of its result, and hipcc's hazard recognizer does not see into inline asm -- the s_nop is that wait
+    // state (seen without it: the fused quad kernel's gate values varying from run to run)
     float d;
     if (HI)
-        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(x));
+        asm("s_nop 1\n\tv_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(x));
     else
-        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(x));
+        asm("s_nop 1\n\tv_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(x));
     return d;
 #endif
 }
@@ -383,7 +386,13 @@ __device__ __forceinline__ float mix_fma(float a, float b, unsigned x) {
 __device__ __forceinline__ float gate_rcp1p_exp2(float y) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y)); }
 // gi as packed fp16 pairs (element 2 p and 2 p + 1 of the C fragment in word p), gh as fp32 C fragments, h the previous state
 __device__ __forceinline__ f32x4 gate_block_bf16(const unsigned (&pr)[2], const unsigned (&pz)[2], const unsigned (&pn)[2],
-                                                 const f32x4 &ar, const f32x4 &az, const f32x4 &an, const f32x4 &hprev) {
+                                                 const f32x4 &ar_, const f32x4 &az_, const f32x4 &an_, const f32x4 &hprev) {
+    // The first readers of the MFMA results below are INLINE-ASM instructions (v_fma_mix_f32): hipcc's hazard recognizer does
+    // not look into them, so nothing keeps them the required wait states behind the last MFMA (seen on MI355X as
+    // run-to-run varying gate values).  This statement takes the accumulators as operands -- so it cannot move above the
+    // MFMAs -- and is the 20 wait states itself (an 8-pass MFMA needs about 11 before a VALU read of its result).
+    f32x4 ar = ar_, az = az_, an = an_;
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(ar), "+v"(az), "+v"(an));
     f32x4 hnew;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {

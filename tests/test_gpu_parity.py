@@ -100,6 +100,21 @@ def test_bf16_against_both_oracles(random_model, test_pcm):
     assert lsb(out, run_oracle(random_model, x)).max() <= 24  # against the unrounded oracle
 
 
+@pytest.mark.parametrize('B,T', [(20, 4), (64, 7), (4096, 2)])
+def test_bf16_results_do_not_vary_from_run_to_run(random_model, B, T):
+    """Two fresh handles, the same input: the same bits.  (The gate arithmetic of the bf16 recurrent kernels reads MFMA and
+    transcendental results from inline-asm v_fma_mix_f32 instructions, which hipcc's hazard recognizer does not see; without the
+    explicit wait states of kns_device.hpp the gate values varied from run to run and were off by ~100 LSB.)"""
+    x = synth_streams(B, T, seed=3)
+    outs = []
+    for _ in range(2):
+        kb = koala_amd.create_batch('key', B, T, 'bf16', model_path=random_model)
+        outs.append(kb.process(x))
+        kb.delete()
+    assert np.array_equal(outs[0], outs[1])
+    assert lsb(outs[0], run_oracle(random_model, x, oracle.PREC_BF16)).max() <= BF16_TOL
+
+
 @pytest.mark.parametrize('B,T,calls', [(256, 16, 2), (1024, 4, 2)])  # (host calls below 4 MiB: not cut into sub-chunks)
 def test_bf16_mask_rms_at_batch_scale(random_model, B, T, calls):
     """north_star's criterion for the bf16 configuration -- mask within 1e-3 RMS of the floating-point (fp32) path -- over
