@@ -353,32 +353,27 @@ __device__ __forceinline__ float gate_fma1(float a, float b, float c) {
     return __builtin_fmaf(a, b, c);
 #endif
 }
-// (float) half HI of the packed fp16 pair x, plus t / times-and-plus: one v_fma_mix_f32 each, one rounding
+// (float) half HI of the packed fp16 pair x, plus t / times-and-plus: one v_fma_mix_f32 each (an f16 operand of an f32 fma), one
+// rounding -- exactly the add / fma on the converted value.  Written as plain fma so that hipcc SELECTS v_fma_mix_f32 itself:
+// as inline asm the instructions were invisible to its hazard recognizer, which then kept no wait states between an MFMA or a
+// transcendental and these readers of its result (gate values varied from run to run), and explicit s_nops cost what the
+// shorter arithmetic had gained.  `one` is 1.0f the optimizer cannot see through (an fma by a literal 1 would be folded into an
+// add of the converted half: two instructions).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float opaque_one() {
+    float one = 1.0f;
+    asm("" : "+v"(one));
+    return one;
+}
 template <int HI>
-__device__ __forceinline__ float mix_add(unsigned x, float t) {
-    float d;
-    if (HI)
-        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(x), "v"(t));
-    else
-        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(x), "v"(t));
-    return d;
+__device__ __forceinline__ float mix_add(unsigned x, float t, float one) {
+    return __builtin_fmaf((float) __builtin_bit_cast(f16x2, x)[HI], one, t);
 }
 template <int HI>
 __device__ __forceinline__ float mix_fma(float a, float b, unsigned x) {
-#ifdef KNS_GATE_UNFUSED
-    return a * b + (float) __builtin_bit_cast(_Float16, (unsigned short) (HI ? x >> 16 : x));
-#else
-    // `a` is usually the result of a transcendental (v_rcp_f32): gfx950 wants a wait state between a transcendental and a
-    // plain VALU reader of its result, and hipcc's hazard recognizer does not see into inline asm -- the s_nop is that wait
-    // state (seen without it: the fused quad kernel's gate values varying from run to run)
-    float d;
-    if (HI)
-        asm("s_nop 1\n\tv_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(x));
-    else
-        asm("s_nop 1\n\tv_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(x));
-    return d;
-#endif
+    return __builtin_fmaf(a, b, (float) __builtin_bit_cast(f16x2, x)[HI]);
 }
+
 // ---- the bf16 configuration's gate arithmetic, shared by every bf16 recurrent kernel.  The operands arrive PRE-SCALED (the
 // constants of the exponentials are folded into the packed weights and biases, kns_layout.h) and the recurrent accumulators
 // start from b_hh, so a hidden unit costs 9 plain vector operations and 6 transcendentals:
@@ -387,17 +382,13 @@ __device__ __forceinline__ float gate_rcp1p_exp2(float y) { return __builtin_amd
 // gi as packed fp16 pairs (element 2 p and 2 p + 1 of the C fragment in word p), gh as fp32 C fragments, h the previous state
 __device__ __forceinline__ f32x4 gate_block_bf16(const unsigned (&pr)[2], const unsigned (&pz)[2], const unsigned (&pn)[2],
                                                  const f32x4 &ar_, const f32x4 &az_, const f32x4 &an_, const f32x4 &hprev) {
-    // The first readers of the MFMA results below are INLINE-ASM instructions (v_fma_mix_f32): hipcc's hazard recognizer does
-    // not look into them, so nothing keeps them the required wait states behind the last MFMA (seen on MI355X as
-    // run-to-run varying gate values).  This statement takes the accumulators as operands -- so it cannot move above the
-    // MFMAs -- and is the 20 wait states itself (an 8-pass MFMA needs about 11 before a VALU read of its result).
-    f32x4 ar = ar_, az = az_, an = an_;
-    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(ar), "+v"(az), "+v"(an));
+    const f32x4 &ar = ar_, &az = az_, &an = an_;
+    const float one = opaque_one();
     f32x4 hnew;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        const float r0 = gate_rcp1p_exp2(mix_add<0>(pr[p], ar[2 * p])), r1 = gate_rcp1p_exp2(mix_add<1>(pr[p], ar[2 * p + 1]));
-        const float z0 = gate_rcp1p_exp2(mix_add<0>(pz[p], az[2 * p])), z1 = gate_rcp1p_exp2(mix_add<1>(pz[p], az[2 * p + 1]));
+        const float r0 = gate_rcp1p_exp2(mix_add<0>(pr[p], ar[2 * p], one)), r1 = gate_rcp1p_exp2(mix_add<1>(pr[p], ar[2 * p + 1], one));
+        const float z0 = gate_rcp1p_exp2(mix_add<0>(pz[p], az[2 * p], one)), z1 = gate_rcp1p_exp2(mix_add<1>(pz[p], az[2 * p + 1], one));
         const float q0 = gate_rcp1p_exp2(mix_fma<0>(r0, an[2 * p], pn[p])), q1 = gate_rcp1p_exp2(mix_fma<1>(r1, an[2 * p + 1], pn[p]));
         const float n0 = __builtin_fmaf(q0, -2.0f, 1.0f), n1 = __builtin_fmaf(q1, -2.0f, 1.0f);
         hnew[2 * p] = __builtin_fmaf(z0, hprev[2 * p] - n0, n0);
