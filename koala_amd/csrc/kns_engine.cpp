@@ -295,10 +295,14 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     dev_synth_seg_ = dev_int("KOALA_AMD_SYNTH_SEG", 0);
     dev_small_mt_ = dev_int("KOALA_AMD_SMALL_MT", 0);
     dev_steps_mt_ = dev_int("KOALA_AMD_STEPS_MT", 192);
-    // A/B arm (developer build only, opt-in): GRU layers as ONE launch fused over CU quads (kns_gruq.hip).  Bit-identical to
-    // the two-kernel form and measured SLOWER at the bench shape (354 against 278 us per layer), so the
-    // product does not take it.
-    use_quad_ = dev_env("KOALA_AMD_QUAD") != nullptr;
+    // GRU layers as ONE launch fused over CU quads (kns_gruq.hip), bit-identical to the two-kernel form.  Taken for ONE-FRAME
+    // calls of large batches, where a CU then pulls a quarter of W_ih and W_hh (300 KiB) per layer instead of a half of one and
+    // all of the other (~740 KiB) and a layer is one launch: 192 against 223 us per 4096-stream frame step; a one-step launch
+    // has no exchange between workgroups at all.  For multi-frame calls it measured slower (354 against 278 us per layer at
+    // 64 frames): there it is an A/B arm of the developer build (KOALA_AMD_QUAD=1; KOALA_AMD_NO_QUAD=1
+    // turns it off everywhere).
+    quad_all_ = dev_env("KOALA_AMD_QUAD") != nullptr;
+    use_quad_ = dev_env("KOALA_AMD_NO_QUAD") == nullptr;
     quad_nb0_max_ = dev_int("KOALA_AMD_QUAD_NB0MAX", 2);
     qdbg_block_ = dev_int("KOALA_AMD_QUAD_DBG", -1);
     // host-pointer calls are cut into sub-chunks of host_chunk_ frames (two staging slots = the Tmax-sized buffers)
@@ -429,9 +433,11 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     d_hseq_a_ = dalloc(M * nbh_ * 1024, true);
     d_hseq_b_ = dalloc(M * nbh_ * 1024, true);
     d_mask_ = (float *) dalloc(M * kMaskTiles * 1024, true);
-    if (use_quad_) {
+    if (use_quad_ && gru_quad_supported(prec_, (int) mtb, 0)) {
         d_xchg_ = dalloc(mtb * kQuadXchgBytesPerMtile, true);  // tags start at 0 = never valid
         d_qerr_ = (unsigned *) dalloc(16, true);
+    } else {
+        use_quad_ = false;
     }
     if (qdbg_block_ >= 0) d_qdbg_ = (unsigned long long *) dalloc((size_t) 8 * 4 * Tmax_ * 8 * 8, true);
     d_in_ = (int16_t *) dalloc((size_t) B_ * Tmax_ * kFrame * 2, true);
@@ -733,7 +739,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     // Chunked bf16 calls whose m-tiles come in whole quads: a GRU layer is ONE launch (kns_gruq.hip) -- input GEMM, recurrent
     // GEMM and gates fused over CU quads, no pre-activation round trip through HBM.  Same arithmetic as the two-kernel form,
     // bit for bit (tests/test_gpu_parity.py::test_alternative_kernels_give_identical_pcm).
-    const bool quad = use_quad_ && !small && !small_steps && T >= 2 && T < 4096;
+    const bool quad = use_quad_ && !small && !small_steps && (T == 1 || (quad_all_ && T < 4096));
     auto gru_quad = [&](const void *a0, int nb0, const void *a1, const void *wih, const float *bih, const void *whh,
                         const float *bhh, int layer, void *hseq) {
         GruQuadArgs g;
@@ -757,9 +763,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         g.dbg_block = qdbg_block_;
         quad_used_ = true;
         tick(kClsGru);
-#ifdef KNS_DEV
         if (only < 0 || only == kClsGru) launch_gru_quad(g, stream_);
-#endif
         tock(kClsGru);
     };
 
@@ -780,13 +784,13 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
             for (int t = 0; t < T; ++t)
                 gru_small(nullptr, 0, d_hseq_a_, d.w_ih_b, d.b_ih_b, d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_, t);
         } else {
-            if (quad && nby <= quad_nb0_max_ && mtb % 4 == 0 && prec_ == kBf16) {
+            if (quad && nby <= quad_nb0_max_) {
                 gru_quad(yprev, nby, d_e_, d.w_ih_a, d.b_ih_a, d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_);
             } else {
                 gemm(kClsGemmIn, yprev, nby, d_e_, nbh_, d.w_ih_a, d.b_ih_a, d_gi_, kGateTiles, 3 * kHidden, kOutGi);
                 gru(d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_);
             }
-            if (quad && mtb % 4 == 0 && prec_ == kBf16) {
+            if (quad) {
                 gru_quad(nullptr, 0, d_hseq_a_, d.w_ih_b, d.b_ih_b, d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_);
             } else {
                 gemm(kClsGemmIn, nullptr, 0, d_hseq_a_, nbh_, d.w_ih_b, d.b_ih_b, d_gi_, kGateTiles, 3 * kHidden, kOutGi);

@@ -326,7 +326,7 @@ import torch  # noqa: F401  (first: see conftest)
 import koala_amd
 from koala_amd.workload import synth_streams
 h = hashlib.sha256()
-for precision, B, T in (('bf16', 4096, 4), ('bf16', 272, 3), ('bf16', 320, 5), ('fp32', 512, 2)):
+for precision, B, T in (('bf16', 4096, 4), ('bf16', 4096, 1), ('bf16', 272, 3), ('bf16', 320, 5), ('fp32', 512, 2)):
     x = np.tile(synth_streams(16, 2 * T, seed=9), ((B + 15) // 16, 1))[:B]
     kb = koala_amd.create_batch('key', B, T, precision, model_path=%(model)r, library_path=%(lib)r)
     for c in range(2):
@@ -354,7 +354,8 @@ def test_alternative_kernels_give_identical_pcm(random_model):
     script = _SWITCH_SCRIPT % {'root': root, 'tests': os.path.join(root, 'tests'), 'model': random_model, 'lib': DEV_LIB}
     for switch in ('', 'KOALA_AMD_GRU_STREAM', 'KOALA_AMD_GEMM_GENERIC',
                    'KOALA_AMD_GEMM_NO_WSR', 'KOALA_AMD_NO_SMALL', 'KOALA_AMD_NO_GRAPH', 'KOALA_AMD_STORE_SPECTRUM',
-                   'KOALA_AMD_DEBUG_TAPS', 'KOALA_AMD_QUAD'):  # (QUAD: GRU layers as one launch fused over CU quads, kns_gruq.hip)
+                   'KOALA_AMD_DEBUG_TAPS', 'KOALA_AMD_QUAD', 'KOALA_AMD_NO_QUAD'):  # (GRU layers as one launch fused over CU quads,
+        # kns_gruq.hip: everywhere / nowhere; the product takes it for one-frame calls of large batches)
         env = dict(os.environ)
         if switch:
             env[switch] = '1'

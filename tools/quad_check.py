@@ -17,19 +17,19 @@ DEV = os.environ.get("QUAD_LIB") or koala_amd.developer_library_path()
 
 
 def make(B, T, quad, model):
-    if quad:
-        os.environ['KOALA_AMD_QUAD'] = '1'
-    else:
-        os.environ.pop('KOALA_AMD_QUAD', None)
+    os.environ.pop('KOALA_AMD_QUAD', None)
+    os.environ.pop('KOALA_AMD_NO_QUAD', None)
+    os.environ['KOALA_AMD_QUAD' if quad else 'KOALA_AMD_NO_QUAD'] = '1'
     kb = koala_amd.create_batch('k', B, T, 'bf16', model_path=model, library_path=DEV)
     os.environ.pop('KOALA_AMD_QUAD', None)
+    os.environ.pop('KOALA_AMD_NO_QUAD', None)
     return kb
 
 
 def main():
     koala_amd.build_native()
     model = params.ensure_params(os.path.join(ROOT, 'build', 'random_1234.kns'), 'random', 1234)
-    shapes = [(64, 2, 2), (64, 7, 2), (320, 5, 2), (1024, 16, 1), (4096, 8, 2)]
+    shapes = [(64, 2, 2), (64, 7, 2), (320, 5, 2), (1024, 16, 1), (4096, 8, 2), (4096, 1, 3)]
     if len(sys.argv) > 1 and sys.argv[1] == 'quick':
         shapes = shapes[:2]
     ok = True
