@@ -823,6 +823,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     sy.pcm = d_pcm;
     sy.hist_in = hist_before;
     sy.recompute = recompute;
+    sy.mask_fp16 = prec_ == kBf16;
     sy.B = B_;
     sy.Bpad = Bpad_;
     sy.T = T;
@@ -1028,6 +1029,23 @@ fail:
 
 // ------------------------------------------------------------------------------------------------ debug taps
 
+static float half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t) (h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    uint32_t u;
+    if (e == 0) {  // zero / subnormal: value = m * 2^-24
+        float f = (float) m * (1.0f / 16777216.0f);
+        memcpy(&u, &f, 4);
+        u |= sign;
+    } else if (e == 31) {
+        u = sign | 0x7f800000u | (m << 13);
+    } else {
+        u = sign | ((e + 112u) << 23) | (m << 13);
+    }
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
 static float bf16_to_float(uint16_t h) {
     uint32_t u = (uint32_t) h << 16;
     float f;
@@ -1100,11 +1118,13 @@ int64_t Engine::debug_read(int what, float *out, int64_t capacity, std::string *
         if (n > capacity) return -2;
         auto h = fetch(d_mask_, (size_t) T * mtb * kMaskTiles * 1024);
         const float *s = (const float *) h.data();
+        const uint16_t *sh = (const uint16_t *) h.data();  // bf16 configuration: fp16 C fragments
         for (int t = 0; t < T; ++t)
             for (int b = 0; b < B_; ++b)
-                for (int k = 0; k < kBins; ++k)
-                    out[((size_t) t * B_ + b) * kBins + k] =
-                        s[(((size_t) t * mtb + b / 16) * kMaskTiles + k / 16) * 256 + cpack_off(b % 16, k % 16)];
+                for (int k = 0; k < kBins; ++k) {
+                    const size_t idx = (((size_t) t * mtb + b / 16) * kMaskTiles + k / 16) * 256 + cpack_off(b % 16, k % 16);
+                    out[((size_t) t * B_ + b) * kBins + k] = prec_ == kBf16 ? half_to_float(sh[idx]) : s[idx];
+                }
     } else if (what == 3) {  // hidden state
         n = (int64_t) kGruLayers * B_ * kHidden;
         if (n > capacity) return -2;

@@ -103,6 +103,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                         const size_t idx = ((size_t) (mt0 + m) * g.ntiles + nt) * 64 + lane;
                         if (OUT == kOutGi)
                             ((typename P::gi_t *) g.out)[idx] = P::to_gi(v);
+                        else if (P::kPrec == kBf16)  // (kOutMask) the bf16 configuration hands the mask over as fp16
+                            ((f16x4 *) g.out)[idx] = __builtin_convertvector(v, f16x4);
                         else
                             ((f32x4 *) g.out)[idx] = v;
                     }
@@ -359,9 +361,11 @@ __global__ __launch_bounds__(512, 2) void gemm_wsr_kernel(GemmArgs g) {
                 // no scalar offset: on gfx950 a 16-byte buffer store WITH an SGPR offset reads its upper data dwords late,
                 // and hipcc 7.2 does not keep the next VALU write of those registers away from it (seen as 2.0 = the
                 // sigmoid's "1 + e" in place of a mask value).
-                const unsigned out_bytes = kApack ? (unsigned) units * 1024u : (unsigned) g.ntiles * 1024u;
+                // (mask tiles are fp16 C fragments: 512 B)
+                constexpr unsigned kTile = kApack ? 1024u : 512u;
+                const unsigned out_bytes = kApack ? (unsigned) units * kTile : (unsigned) g.ntiles * kTile;
                 const char *out_mt = (const char *) g.out + (size_t) (valid ? mt : 0) * out_bytes;
-                const unsigned tile_bytes = valid ? 1024u : 0u;
+                const unsigned tile_bytes = valid ? kTile : 0u;
                 const frag_t *ab = abuf + (cur * kStageBlocks + m * NB) * 64;
                 frag_t a[NB];
 #pragma unroll
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wsr_kernel(GemmArgs g) {
                             v[i] = x;
                         }
                         if (!kApack) {
-                            buf_store_f32x4(make_rsrc(out_mt + (size_t) nt * 1024, tile_bytes), lane16, v);
+                            buf_store_gi(make_rsrc(out_mt + (size_t) nt * 512, tile_bytes), lane * 8u, 0, __builtin_convertvector(v, f16x4));
                         } else {
                             uint16_t *sc = (uint16_t *) scratch;
 #pragma unroll

@@ -40,7 +40,7 @@ void launch_analysis(const AnalysisArgs &a, hipStream_t s);
 // ---- synthesis: mask x spectrum -> iFFT -> window -> overlap-add -> int16
 struct SynthesisArgs {
     const float *spec;      // as above
-    const float *mask;      // C-packed fp32 [T*mtiles][17][64][4]
+    const float *mask;      // C-packed [T*mtiles][17][64][4]: fp32, or fp16 (mask_fp16: the bf16 configuration's mask storage type)
     const float *window;    // [512]
     const float *twiddle;   // [512][2]
     const float *tail_in;   // [Bpad][256] overlap-add state left by the previous call
@@ -51,13 +51,14 @@ struct SynthesisArgs {
     const int16_t *pcm;     // recompute != 0: the call's input [B][T*256] ...
     const int16_t *hist_in; // ... and the history the analysis kernel started from, [Bpad][256]
     int recompute;          // rebuild each frame's spectrum from its PCM instead of reading `spec`
+    int mask_fp16 = 0;
 };
 void launch_synthesis(const SynthesisArgs &a, hipStream_t s);
 
 // ---- GEMM over all stream-frames: out = act(A . W + bias), A from up to two A-packed sources
 enum GemmOut {
     kOutGi = 0,        // C-packed pre-activations (fp32 or fp16), no activation
-    kOutMask = 1,      // C-packed fp32, sigmoid
+    kOutMask = 1,      // C-packed, sigmoid: fp32 (fp32 configuration) or fp16 (bf16 configuration: half the bytes of the mask hand-off)
     kOutAPlain = 2,    // A-packed operand type, no activation
     kOutASigmoid = 3,  // A-packed operand type, sigmoid
 };

@@ -193,7 +193,7 @@ void launch_analysis(const AnalysisArgs &a, hipStream_t s) {
 // updates the history in place and the previous frame is gone by the time this kernel runs.
 // (three waves per SIMD: the kernel is bound by VALU issue, and two waves on a SIMD reach an instruction every ~2.8 cycles,
 // three come close to the pipe's 2; the register budget of 168 is what decides which loads are prefetched below)
-template <bool kRecompute>
+template <bool kRecompute, bool kMaskH>  // kMaskH: the mask travels as fp16 C fragments (bf16 configuration), else fp32
 __global__ __launch_bounds__(256, 3) void synthesis_kernel(SynthesisArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -234,6 +234,16 @@ __global__ __launch_bounds__(256, 3) void synthesis_kernel(SynthesisArgs g) {
     const unsigned mlane = ((unsigned) (wave * 16 + c) * 4u + (unsigned) q) * 4u;
     float mk[17], mkn[17];
     auto mask_fetch = [&](float (&m)[17], int t) {
+        if (kMaskH) {  // fp16 tiles of 512 B; the conversion to fp32 is exact
+            const __amdgpu_buffer_rsrc_t mr =
+                make_rsrc((const char *) g.mask + ((size_t) t * mtiles + mt) * kMaskTiles * 512, kMaskTiles * 512);
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2)
+                m[k2] = (float) __builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(mr, mlane >> 1, k2 * 512u, 0));
+            m[16] = (float) __builtin_bit_cast(
+                _Float16, __builtin_amdgcn_raw_buffer_load_b16(mr, ((unsigned) (wave * 16) * 4u + (unsigned) q) * 2u, 16 * 512u, 0));
+            return;
+        }
         const __amdgpu_buffer_rsrc_t mr = make_rsrc(g.mask + ((size_t) t * mtiles + mt) * kMaskTiles * 256, kMaskTiles * 1024);
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2)
@@ -354,10 +364,14 @@ __global__ __launch_bounds__(256, 3) void synthesis_kernel(SynthesisArgs g) {
 void launch_synthesis(const SynthesisArgs &a, hipStream_t s) {
     const size_t lds = kOffStftEnd;
     const dim3 grid(a.Bpad / 16, (a.T + a.seg - 1) / a.seg);
-    if (a.recompute)
-        hipLaunchKernelGGL(synthesis_kernel<true>, grid, dim3(256), lds, s, a);
+    if (a.recompute && a.mask_fp16)
+        hipLaunchKernelGGL((synthesis_kernel<true, true>), grid, dim3(256), lds, s, a);
+    else if (a.recompute)
+        hipLaunchKernelGGL((synthesis_kernel<true, false>), grid, dim3(256), lds, s, a);
+    else if (a.mask_fp16)
+        hipLaunchKernelGGL((synthesis_kernel<false, true>), grid, dim3(256), lds, s, a);
     else
-        hipLaunchKernelGGL(synthesis_kernel<false>, grid, dim3(256), lds, s, a);
+        hipLaunchKernelGGL((synthesis_kernel<false, false>), grid, dim3(256), lds, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------ reset

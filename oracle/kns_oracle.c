@@ -549,7 +549,7 @@ static void frame_block(const kns_params_t *p, int nb, kns_stream_t **st, const 
         for (int s = 0; s < nb; ++s)
             for (int j = 0; j < g->d_out; ++j) {
                 float v = kns_sigmoid(w->y[s][j]);
-                if (bf && sg < KNS_STAGES - 1) v = kns_round_bf16(v);
+                if (bf) v = sg < KNS_STAGES - 1 ? kns_round_bf16(v) : kns_round_fp16(v); /* GEMM operand / the mask's fp16 hand-off */
                 w->y[s][j] = v;
             }
         if (taps && taps->heads) memcpy(taps->heads + tap_off, &w->y[0][0], sizeof(float) * (size_t) g->d_out);
