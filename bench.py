@@ -323,7 +323,8 @@ def main():
               file=sys.stderr)
         sys.exit(2)
     world = 1
-    if world_env > 1:
+    collective = None
+    if world_env > 1 or 'RANK' in os.environ:  # started by a launcher (torchrun, or launch_ranks above): even one rank joins a group
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -333,6 +334,7 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)
         world = dist.get_world_size()  # what the communicator was actually built with
+        collective = dist.get_backend()
     else:
         torch.cuda.set_device(local_rank)
 
@@ -356,7 +358,7 @@ def main():
         kb.process_device(T, dx.data_ptr(), dy.data_ptr())
 
     def barrier():
-        if world > 1:
+        if collective:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -540,7 +542,7 @@ def main():
         del src, dst
 
     kb.delete()
-    if world > 1:
+    if collective:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
@@ -564,6 +566,7 @@ def main():
                         % (B, T, args.precision),
             'streams_per_gpu': B, 'frames_per_call': T, 'global_streams': B * world,
             'parallelism': 'streams sharded over %d GPU(s), no data-path collective' % world,
+            'throughput_all_reduce': collective,  # 'nccl' (= RCCL) under a launcher, None for a plain single-process run
         },
         'real_time_factor': round(elapsed_max / (args.steps * T * 256 / 16000.0) / B, 9),
         'frames_per_sec_per_gpu': round(value / world, 1),

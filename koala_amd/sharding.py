@@ -20,13 +20,15 @@ def aggregate_throughput(frames_local: int, elapsed_local: float, device: Option
     """
     All-reduce of the per-rank counters: returns (total frames over all ranks, slowest rank's elapsed seconds).
     Uses the default torch.distributed group (backend `nccl` = RCCL over xGMI on GPUs, `gloo` on CPU); a
-    single-process run passes through unchanged.
+    run without a process group passes through unchanged.
     """
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return int(frames_local), float(elapsed_local)
+    # (a one-rank group still goes through the collective: `torchrun --nproc-per-node 1` on a single-GPU box is how the RCCL
+    # branch -- communicator creation on the device, all-reduce of device tensors -- gets executed at all)
     dev = device or ("cuda" if dist.get_backend() == "nccl" else "cpu")
     frames = torch.tensor([frames_local], dtype=torch.int64, device=dev)
     elapsed = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)

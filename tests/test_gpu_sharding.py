@@ -89,3 +89,20 @@ def test_bench_launches_its_own_ranks():
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['config']['global_streams'] == 1024
     assert abs(line['value'] - 1024 * 8 * 3 / (line['ms_per_step'] * 3e-3)) / line['value'] < 1e-3
+
+
+def test_rccl_branch_runs_with_one_rank_under_torchrun():
+    """The driver starts multi-GPU runs as `python -m torch.distributed.run ... bench.py --gpus N` with backend nccl (= RCCL).
+    A one-GPU box cannot host two RCCL ranks, but it can host ONE: communicator creation on the device
+    (`init_process_group('nccl', device_id=...)`), the barriers and the all-reduce of device tensors all execute."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+                          '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1',
+                          '--prime-seconds', '0', '--sustain-seconds', '0', '--streams', '512', '--frames', '8', '--no-cpu-baseline',
+                          '--no-extra'], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 1 and line['config']['throughput_all_reduce'] == 'nccl'
+    assert abs(line['value'] - 512 * 8 * 3 / (line['ms_per_step'] * 3e-3)) / line['value'] < 1e-3
