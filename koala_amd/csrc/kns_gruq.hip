@@ -494,6 +494,179 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad_kernel(GruQuadArgs g
         q_h_wave(g, cx, wave - 4);
 }
 
+// ------------------------------------------------------------------------------------------------ one-step form
+//
+// One frame per call (T = 1): the same decomposition -- workgroup c of a quad holds the W_ih and W_hh columns of hidden units
+// 64 c .. 64 c + 63 and serves unit tile 16 for m-tile c, so a CU pulls 300 KiB of weights per layer instead of ~740 -- but no
+// recurrence, hence no exchange between workgroups, no rings and no phases: stage everything, two barriers, done.
+//   prologue   unit tile 16's W_ih -> LDS; h_{-1} of the four m-tiles -> four operand images; x of the four m-tiles -> LDS; every
+//              wave its resident weights (h waves 0..2 also one gate of unit tile 16's W_hh: used once, straight into registers)
+//   barrier A
+//   x waves    x . W_ih + b_ih of the four blocks -> fp16 in LDS (wave 3: + unit tile 16's where m = c, kept in registers)
+//   h waves    h . W_hh of the four blocks, accumulators (starting from b_hh) kept in registers (waves 0..2: + one gate of unit
+//              tile 16 where m = c -> LDS)
+//   barrier B
+//   h waves    gates of the four blocks -> hidden state (fp32) and hidden sequence (operand words); x wave 3: unit tile 16's
+// Bit for bit the arithmetic of every other bf16 path.
+constexpr int kQ1OffHs = 0;                            // [4] operand images of h_{-1}
+constexpr int kQ1OffXs = 4 * kQHsBytes;                // [4][NBX] KiB (sized for NBX = 11)
+constexpr int kQ1OffGi = kQ1OffXs + 4 * 11 * 1024;     // [4 blocks][4 pairs][3 gates][64][8 B]
+constexpr int kQ1OffGh16 = kQ1OffGi + 4 * 4 * 1536;    // [3][64][16 B]
+constexpr int kQ1OffW16x = kQ1OffGh16 + 3072;          // [3 gates][NBX] KiB
+constexpr int kQ1Lds = kQ1OffW16x + 3 * 11 * 1024;
+
+template <int NB0>
+__global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad1_kernel(GruQuadArgs g) {
+    typedef bf16x8 frag_t;
+    constexpr int NBX = 9 + NB0;
+    __shared__ __attribute__((aligned(16))) char smem[kQ1Lds];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x;
+    const int c = (bid >> 3) & 3, colq = lane & 15;
+    const int qq = g.quad0 + (bid >> 5) * 8 + (bid & 7);
+    if (qq >= (g.mtiles >> 2)) return;
+    const int mt0 = 4 * qq;
+    const bool even = (lane & 1) == 0;
+    const int lane_off = ((lane >> 4) * 4 + (even ? 0 : 2) + 16 * ((colq & ~1) >> 3)) * 16 + ((colq & ~1) & 7) * 2;
+    const int j = wave & 3, u = 4 * c + j;
+
+    // ---- resident weights first (the longest loads), then the staging
+    frag_t w[33];   // x waves: W_ih tile u [3 gates][NBX]; h waves: W_hh tile u [9][3 gates]
+    frag_t w16[9];  // h waves 0..2: gate j of unit tile 16's W_hh
+    float b0, b1, b2, b16 = 0.f;
+    if (wave < 4) {
+        const frag_t *wih = (const frag_t *) g.wih;
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+            for (int blk = 0; blk < NBX; ++blk) w[gt * NBX + blk] = wih[((size_t) (u * 3 + gt) * NBX + blk) * 64 + lane];
+        b0 = g.bih[(u * 3 + 0) * 16 + colq];
+        b1 = g.bih[(u * 3 + 1) * 16 + colq];
+        b2 = g.bih[(u * 3 + 2) * 16 + colq];
+    } else {
+        const frag_t *whh = (const frag_t *) g.whh;
+#pragma unroll
+        for (int i = 0; i < 27; ++i) w[i] = whh[((size_t) (u * 3 + i % 3) * 9 + i / 3) * 64 + lane];
+        const int g16 = j < 3 ? j : 0;
+#pragma unroll
+        for (int blk = 0; blk < 9; ++blk) w16[blk] = whh[((size_t) (16 * 3 + g16) * 9 + blk) * 64 + lane];
+        b0 = g.bhh[(u * 3 + 0) * 16 + colq];
+        b1 = g.bhh[(u * 3 + 1) * 16 + colq];
+        b2 = g.bhh[(u * 3 + 2) * 16 + colq];
+        b16 = g.bhh[(16 * 3 + g16) * 16 + colq];
+    }
+    for (int i = wave; i < 3 * NBX; i += kQWaves)
+        ((frag_t *) (smem + kQ1OffW16x))[i * 64 + lane] = ((const frag_t *) g.wih)[((size_t) 48 * NBX + i) * 64 + lane];
+    for (int i = tid; i < 4 * kQHsBytes / 16; i += 64 * kQWaves) ((uint4 *) (smem + kQ1OffHs))[i] = uint4{0, 0, 0, 0};
+    for (int i = wave; i < 4 * NBX; i += kQWaves) {
+        const int m = i / NBX, k = i % NBX;
+        const frag_t *src = k < NB0 ? (const frag_t *) g.a0 + ((size_t) (mt0 + m) * NB0 + k) * 64
+                                    : (const frag_t *) g.a1 + ((size_t) (mt0 + m) * 9 + (k - NB0)) * 64;
+        ((frag_t *) (smem + kQ1OffXs))[(m * 11 + k) * 64 + lane] = src[lane];
+    }
+    __syncthreads();  // (the images are zero before the tiles go in: k-block 8's upper half must stay zero)
+    for (int idx = wave; idx < 4 * kUnitTiles; idx += kQWaves) {
+        const int m = idx / kUnitTiles, t = idx % kUnitTiles;
+        const f32x4 hv = ((const f32x4 *) g.hstate_in)[((size_t) (mt0 + m) * kUnitTiles + t) * 64 + lane];
+        unsigned w0, w1;
+        q_pack(hv, even, w0, w1);
+        char *img = smem + kQ1OffHs + m * kQHsBytes + q_tile_off(t) + lane_off;
+        *(unsigned *) img = w0;
+        *(unsigned *) (img + 16) = w1;
+    }
+    __syncthreads();  // barrier A
+
+    // one tile of h_0 of m-tile m: fp32 state, operand words of the hidden sequence
+    auto emit = [&](int m, int tile, const f32x4 &hnew) {
+        ((f32x4 *) g.hstate_out)[((size_t) (mt0 + m) * kUnitTiles + tile) * 64 + lane] = hnew;
+        unsigned w0, w1;
+        q_pack(hnew, even, w0, w1);
+        char *hs = (char *) g.hseq + (size_t) (mt0 + m) * kQHsBytes + q_tile_off(tile) + lane_off;
+        *(unsigned *) hs = w0;
+        *(unsigned *) (hs + 16) = w1;
+    };
+
+    if (wave < 4) {
+        const frag_t(&wx)[3][NBX] = *(const frag_t(*)[3][NBX]) & w[0];
+        u32x2 gi16[3] = {u32x2{0, 0}, u32x2{0, 0}, u32x2{0, 0}};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const frag_t *xa = (const frag_t *) (smem + kQ1OffXs + m * 11 * 1024);
+            f32x4 acc[3];
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            q_x_mma<NBX>(acc, xa, wx, lane);
+            char *ring = smem + kQ1OffGi + ((m * 4 + j) * 3) * 512 + lane * 8;
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt) {
+                const float b = gt == 0 ? b0 : gt == 1 ? b1 : b2;
+                f32x4 v = acc[gt];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = v[i] + b;
+                *(f16x4 *) (ring + gt * 512) = PBF16::to_gi(v);
+            }
+            if (j == 3 && m == c) {
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                q_x_mma16<NBX>(acc, xa, (const frag_t *) (smem + kQ1OffW16x), lane);
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt) {
+                    const float b = g.bih[(16 * 3 + gt) * 16 + colq];
+                    f32x4 v = acc[gt];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = v[i] + b;
+                    gi16[gt] = __builtin_bit_cast(u32x2, PBF16::to_gi(v));
+                }
+            }
+        }
+        __syncthreads();  // barrier B
+        if (j == 3) {  // unit tile 16 of m-tile c
+            const char *gh = smem + kQ1OffGh16 + lane * 16;
+            f32x4 acc[3];
+            acc[0] = *(const f32x4 *) gh;
+            acc[1] = *(const f32x4 *) (gh + 1024);
+            acc[2] = *(const f32x4 *) (gh + 2048);
+            const f32x4 h16 = ((const f32x4 *) g.hstate_in)[((size_t) (mt0 + c) * kUnitTiles + 16) * 64 + lane];
+            emit(c, 16, q_gates(acc, gi16[0], gi16[1], gi16[2], h16));
+        }
+        return;
+    }
+
+    // ---- h waves
+    const frag_t(&wh)[27] = *(const frag_t(*)[27]) & w[0];
+    f32x4 acc[4][3];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        acc[m][0] = f32x4{b0, b0, b0, b0};  // the recurrent chains start from b_hh
+        acc[m][1] = f32x4{b1, b1, b1, b1};
+        acc[m][2] = f32x4{b2, b2, b2, b2};
+        const frag_t *ha = (const frag_t *) (smem + kQ1OffHs + m * kQHsBytes);
+        if (m == c && j < 3) {  // one gate of unit tile 16 rides along (its weights are in registers: plain chain here)
+            f32x4 a16 = f32x4{b16, b16, b16, b16};
+#pragma unroll
+            for (int blk = 0; blk < 9; ++blk) {
+                const frag_t a = ha[blk * 64 + lane];
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt) acc[m][gt] = PBF16::mma(a, wh[blk * 3 + gt], acc[m][gt]);
+                a16 = PBF16::mma(a, w16[blk], a16);
+            }
+            *(f32x4 *) (smem + kQ1OffGh16 + j * 1024 + lane * 16) = a16;
+        } else {
+            f32x4 dummy = f32x4{0.f, 0.f, 0.f, 0.f};
+            q_h_mma<false>(acc[m], dummy, ha, wh, (const frag_t *) nullptr, lane);
+        }
+    }
+    __syncthreads();  // barrier B
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const char *ring = smem + kQ1OffGi + ((m * 4 + j) * 3) * 512 + lane * 8;
+        const u32x2 pr = *(const u32x2 *) ring, pz = *(const u32x2 *) (ring + 512), pn = *(const u32x2 *) (ring + 1024);
+        const f32x4 hprev = ((const f32x4 *) g.hstate_in)[((size_t) (mt0 + m) * kUnitTiles + u) * 64 + lane];
+        emit(m, u, q_gates(acc[m], pr, pz, pn, hprev));
+    }
+}
+
 bool gru_quad_supported(int precision, int mtiles, int nb0) {
     return precision == kBf16 && mtiles >= 4 && mtiles % 4 == 0 && nb0 >= 0 && nb0 <= 2;
 }
@@ -505,6 +678,15 @@ void launch_gru_quad(const GruQuadArgs &a, hipStream_t s) {
         g.quad0 = q0;
         const int n = nquads - q0 < 64 ? nquads - q0 : 64;
         const dim3 grid((n + 7) / 8 * 32), block(64 * kQWaves);  // 32 workgroups = 8 quads, one per XCD
+        if (a.T == 1) {  // one step: no exchange, no phases (gru_quad1_kernel)
+            if (a.nb0 == 0)
+                hipLaunchKernelGGL(gru_quad1_kernel<0>, grid, block, 0, s, g);
+            else if (a.nb0 == 1)
+                hipLaunchKernelGGL(gru_quad1_kernel<1>, grid, block, 0, s, g);
+            else
+                hipLaunchKernelGGL(gru_quad1_kernel<2>, grid, block, 0, s, g);
+            continue;
+        }
         if (a.nb0 == 0)
             hipLaunchKernelGGL(gru_quad_kernel<0>, grid, block, 0, s, g);
         else if (a.nb0 == 1)
