@@ -499,6 +499,157 @@ __global__ __launch_bounds__(512, 2) void gemm_head_kernel(GemmArgs g) {
     }
 }
 
+// ---- weight-stationary form of the five-frame front-end (KNS-v1.1, bf16): out[t] = sum_tau feat[t - 4 + tau] . W_tau + b,
+// K = 5 x 9 k-blocks, N = 18 n-tiles.  The 810 KiB weight image does not fit a CU, a third of its n-tiles does: the three
+// workgroups of a triple (blocks b, b + 8, b + 16: one XCD, so the partners' reads of the feature tiles hit its L2) take six
+// n-tiles = three A-packed output units each, one n-tile with all 45 of its k-blocks per wave (180 VGPRs).  A workgroup
+// walks TIME for one tile of 16 streams: output frame t needs the feature tiles of frames t .. t + 4 of the buffer
+// [context | call], so a ring of feature tiles in LDS takes one new tile per frame; kF5P frames are worked per barrier (with
+// more than one, a fragment read from LDS feeds every frame's chain it belongs to: tile t0 + i is tap i - m of frame t0 + m).
+// Every chain is k-ascending from a zero accumulator, bias after it: the same arithmetic as gemm_kernel, bit for bit.
+// Measured (4 096 streams x 64 frames): ~205 us against 1 050 for gemm_kernel, which re-streams the weights per 32 rows; 1, 2, 3
+// or 4 frames per barrier and a request distance of 1 or 2 stages all within 5 % -- the kernel is bound by the MFMA issue of
+// the two SIMDs that carry two of the six waves (2 x 45 x 16 cycles per frame).
+constexpr int kF5Waves = 6;
+constexpr int kF5Taps = 5;
+#ifndef F5_P
+#define F5_P 1
+#endif
+#ifndef F5_RING
+#define F5_RING 8
+#endif
+#ifndef F5_ABL
+#define F5_ABL 0  // timing ablations (tools/front5_time.py; garbage out): 1 no feature prefetch, 2 no MFMAs, 4 no output stores
+#endif
+#ifndef F5_DEPTH
+#define F5_DEPTH 2
+#endif
+constexpr int kF5Depth = F5_DEPTH;            // stages between the request for a feature tile and the stage that reads it
+constexpr int kF5P = F5_P;                    // output frames per barrier
+constexpr int kF5Ring = F5_RING;              // feature tiles in LDS: kF5P + 4 being read, kF5P being filled
+constexpr int kF5TileBytes = PBF16::NBH * 1024;
+constexpr int kF5OutBytes = kF5P * 3 * 1024;  // one parity of the output transposer: kF5P frames x 3 units
+constexpr int kF5LdsBytes = kF5Ring * kF5TileBytes + 2 * kF5OutBytes;
+
+__global__ __launch_bounds__(64 * kF5Waves) void gemm_front5_kernel(GemmArgs g, int mtb, int T, int seglen) {
+    typedef PBF16 P;
+    typedef P::frag_t frag_t;
+    constexpr int NB = P::NBH;
+    static_assert(kF5Ring >= 2 * kF5P + kF5Taps - 1, "ring");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    const int job = (b / 24) * 8 + (b & 7), c = (b >> 3) % 3;
+    const int nseg = (T + seglen - 1) / seglen;
+    if (job >= mtb * nseg) return;
+    const int st = job % mtb, seg = job / mtb;
+    const int t_begin = seg * seglen, t_end = min(T, t_begin + seglen);
+    const int colq = lane & 15;
+    const int nt = 6 * c + wave;
+
+    frag_t wr[kF5Taps * NB];
+    {
+        const frag_t *w = (const frag_t *) g.w + (size_t) nt * (kF5Taps * NB) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < kF5Taps * NB; ++k) wr[k] = w[k * 64];
+    }
+    const float bias = g.bias[nt * 16 + colq];
+    const bool pad = nt * 16 + colq >= g.n_valid;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the resident loads are complete before the loop (see kns_gruq.hip)
+
+    // feature tile i of the buffer [context | call] for this stream tile; past the end: a descriptor of zero bytes (reads 0)
+    const char *feat = (const char *) g.a1;
+    const int ntile_i = T + kF5Taps - 1;
+    auto tile_rsrc = [&](int i) {
+        const bool ok = i < ntile_i;
+        return make_rsrc(feat + ((size_t) (ok ? i : 0) * mtb + st) * kF5TileBytes, ok ? (unsigned) kF5TileBytes : 0u);
+    };
+    const unsigned lane16 = lane * 16u;
+    frag_t *ring = (frag_t *) smem;
+    // prologue: tiles t_begin .. t_begin + kF5P + 3 (what the first stage reads)
+    for (int f = wave; f < (kF5P + kF5Taps - 1) * NB; f += kF5Waves) {
+        const int j = f / NB, kb = f - j * NB;
+        ring[(((t_begin + j) % kF5Ring) * NB + kb) * 64 + lane] = buf_load_frag(tile_rsrc(t_begin + j), lane16, kb * 1024u);
+    }
+    __syncthreads();
+
+    constexpr int kFetch = (kF5P * NB + kF5Waves - 1) / kF5Waves;
+    // Feature tiles are requested kF5Depth stages before the stage that reads them (a global load takes ~1.5 us here, a stage
+    // ~1.4): they wait in registers, set (stage mod kF5Depth), and go into the ring at the end of the stage before theirs.
+    frag_t stage[kF5Depth][kFetch];
+    auto request = [&](auto set_tag, int tfirst) {  // the kF5P new tiles of the stage whose first frame is tfirst
+        constexpr int kSet = decltype(set_tag)::value;
+#pragma unroll
+        for (int q = 0; q < kFetch; ++q) {
+            const int f = wave + kF5Waves * q;
+            const int j = f / NB, kb = f - j * NB;
+            if (F5_ABL & 1)
+                stage[kSet][q] = wr[q];
+            else if (f < kF5P * NB)
+                stage[kSet][q] = buf_load_frag(tile_rsrc(tfirst + kF5Taps - 1 + j), lane16, kb * 1024u);
+        }
+    };
+    auto body = [&](auto set_req, auto set_put, int t0, int par) {
+        request(set_req, t0 + kF5Depth * kF5P);
+        f32x4 acc[kF5P];
+#pragma unroll
+        for (int m = 0; m < kF5P; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < kF5P + kF5Taps - 1; ++i) {
+            const frag_t *tile = ring + (((t0 + i) % kF5Ring) * NB) * 64 + lane;
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+                const frag_t a = tile[kb * 64];
+#pragma unroll
+                for (int m = 0; m < kF5P; ++m)
+                    if (i - m >= 0 && i - m < kF5Taps) {
+                        if (F5_ABL & 2)
+                            acc[m][0] += (float) a[0] * (float) wr[(i - m) * NB + kb][1];
+                        else
+                            acc[m] = P::mma(a, wr[(i - m) * NB + kb], acc[m]);
+                    }
+            }
+        }
+        char *outb = smem + kF5Ring * kF5TileBytes + par * kF5OutBytes;
+#pragma unroll
+        for (int m = 0; m < kF5P; ++m) {
+            uint16_t *sc = (uint16_t *) (outb + (m * 3 + (wave >> 1)) * 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float x = pad ? 0.0f : acc[m][i] + bias;
+                sc[P::off((lane >> 4) * 4 + i, (wave & 1) * 16 + colq)] = P::cvt(x);
+            }
+        }
+        // the next stage's new tiles (requested kF5Depth - 1 stages ago) into the ring: their slots were last read a stage ago
+        constexpr int kPut = decltype(set_put)::value;
+#pragma unroll
+        for (int q = 0; q < kFetch; ++q) {
+            const int f = wave + kF5Waves * q;
+            const int j = f / NB, kb = f - j * NB;
+            if (f < kF5P * NB) ring[(((t0 + kF5P + kF5Taps - 1 + j) % kF5Ring) * NB + kb) * 64 + lane] = stage[kPut][q];
+        }
+        __syncthreads();
+        // finished output tiles: kF5P frames x 3 units (descriptor of zero bytes for a frame past the segment)
+#pragma unroll
+        for (int q = wave; q < kF5P * 3 && !(F5_ABL & 4); q += kF5Waves) {
+            const int m = q / 3, ul = q - 3 * m;
+            const int t = t0 + m;
+            const bool ok = t < t_end;
+            const char *dst = (const char *) g.out + (((size_t) (ok ? t : 0) * mtb + st) * (g.ntiles / 2) + 3 * c + ul) * 1024;
+            buf_store_frag(make_rsrc(dst, ok ? 1024u : 0u), lane16, ((const frag_t *) (outb + (m * 3 + ul) * 1024))[lane]);
+        }
+    };
+    static_assert(kF5Depth == 1 || kF5Depth == 2, "register sets alternate");
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, kF5Depth - 1> S1;
+    if (kF5Depth == 2) request(S1{}, t_begin + kF5P);  // stage 1's tiles; stage 0's went into the ring in the prologue
+    for (int t0 = t_begin; t0 < t_end; t0 += 2 * kF5P) {
+        body(S0{}, S1{}, t0, 0);
+        if (t0 + kF5P < t_end) body(S1{}, S0{}, t0 + kF5P, 1);
+    }
+}
+
 template <class P, int MT>
 static void launch_gemm_mt(const GemmArgs &a, hipStream_t s) {
     const int nb = a.nb0 + a.taps * a.nb1;
@@ -571,6 +722,27 @@ void launch_gemm(const GemmArgs &a, hipStream_t s) {
         return;
     }
     const bool no_wsr = (a.dev & kDevGemmNoWsr) != 0;  // A/B switch (developer build only)
+    if (a.precision == kBf16 && a.nb0 == 0 && a.nb1 == PBF16::NBH && a.taps == kF5Taps && a.out_kind == kOutAPlain && a.ntiles == 18 &&
+        a.tap_stride % ((size_t) a.nb1 * 1024) == 0 && !no_wsr) {
+        const int mtb = (int) (a.tap_stride / ((size_t) a.nb1 * 1024));  // m-tiles (of 16 streams) per frame
+        const int T = mtb > 0 ? a.mtiles / mtb : 0;
+        if (T >= 8 && a.mtiles == T * mtb) {
+            // one workgroup triple per (stream tile, time segment); segments only when the stream tiles alone do not fill the chip
+            int nseg = 1;
+            while (mtb * nseg < 256 && T / (nseg * 2) >= 16) nseg *= 2;
+            int seglen = (T + nseg - 1) / nseg;
+            seglen = (seglen + kF5P - 1) / kF5P * kF5P;
+            nseg = (T + seglen - 1) / seglen;
+            const int jobs = mtb * nseg;
+            static bool attr = false;
+            if (!attr) {
+                (void) hipFuncSetAttribute((const void *) gemm_front5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kF5LdsBytes);
+                attr = true;
+            }
+            hipLaunchKernelGGL(gemm_front5_kernel, dim3((jobs + 7) / 8 * 24), dim3(64 * kF5Waves), kF5LdsBytes, s, a, mtb, T, seglen);
+            return;
+        }
+    }
     if (a.precision == kBf16 && a.nb0 == 0 && a.nb1 == PBF16::NBH && a.taps == 1 && a.mtiles >= 512 && !no_wsr) {
         const dim3 grid(256), block(512);
         if (a.out_kind == kOutAPlain && a.ntiles <= 32) {

@@ -23,7 +23,7 @@ def lsb(a, b):
 
 
 @pytest.mark.parametrize('precision,B,T,calls', [('fp32', 19, 3, 3), ('fp32', 1, 1, 7), ('bf16', 40, 8, 2), ('bf16', 272, 2, 4),
-                                                ('bf16', 4096, 4, 2)])
+                                                ('bf16', 4096, 4, 2), ('bf16', 272, 9, 2), ('bf16', 48, 37, 2), ('bf16', 512, 16, 2)])
 def test_five_frame_front_end_matches_the_oracle(random5_model, precision, B, T, calls):
     prec = oracle.PREC_BF16 if precision == 'bf16' else oracle.PREC_FP32
     x = synth_streams(B, T * calls, seed=300 + B)

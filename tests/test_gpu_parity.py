@@ -332,11 +332,18 @@ for precision, B, T in (('bf16', 4096, 4), ('bf16', 4096, 1), ('bf16', 272, 3), 
     for c in range(2):
         h.update(kb.process(np.ascontiguousarray(x[:, c * T * 256:(c + 1) * T * 256])).tobytes())
     kb.delete()
+# the five-frame front-end (KNS-v1.1): weight-stationary over workgroup triples vs the generic GEMM, ragged segment ends
+for B, T in ((272, 9), (48, 37), (1024, 8)):
+    x = np.tile(synth_streams(16, 2 * T, seed=11), ((B + 15) // 16, 1))[:B]
+    kb = koala_amd.create_batch('key', B, T, 'bf16', model_path=%(model5)r, library_path=%(lib)r)
+    for c in range(2):
+        h.update(kb.process(np.ascontiguousarray(x[:, c * T * 256:(c + 1) * T * 256])).tobytes())
+    kb.delete()
 print('DIGEST', h.hexdigest())
 '''
 
 
-def test_alternative_kernels_give_identical_pcm(random_model):
+def test_alternative_kernels_give_identical_pcm(random_model, random5_model):
     """Every A/B switch selects other kernels for the same arithmetic (weight-streaming vs resident recurrent kernels, the
     generic vs weight-stationary GEMMs, stored vs recomputed spectrum, ...): the PCM must not change by a bit."""
     import os
@@ -346,12 +353,13 @@ def test_alternative_kernels_give_identical_pcm(random_model):
     digests = {}
     # the product library (which reads no switch) is one arm, the developer build under each of its switches the others
     script = _SWITCH_SCRIPT % {'root': root, 'tests': os.path.join(root, 'tests'), 'model': random_model,
-                               'lib': koala_amd.default_library_path()}
+                               'model5': random5_model, 'lib': koala_amd.default_library_path()}
     out = subprocess.run([sys.executable, '-c', script], env=dict(os.environ, KOALA_AMD_GEMM_GENERIC='1'),
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     digests['product'] = [ln for ln in out.stdout.splitlines() if ln.startswith('DIGEST')][-1]
-    script = _SWITCH_SCRIPT % {'root': root, 'tests': os.path.join(root, 'tests'), 'model': random_model, 'lib': DEV_LIB}
+    script = _SWITCH_SCRIPT % {'root': root, 'tests': os.path.join(root, 'tests'), 'model': random_model, 'model5': random5_model,
+                               'lib': DEV_LIB}
     for switch in ('', 'KOALA_AMD_GRU_STREAM', 'KOALA_AMD_GEMM_GENERIC',
                    'KOALA_AMD_GEMM_NO_WSR', 'KOALA_AMD_NO_SMALL', 'KOALA_AMD_NO_GRAPH', 'KOALA_AMD_STORE_SPECTRUM',
                    'KOALA_AMD_DEBUG_TAPS', 'KOALA_AMD_QUAD', 'KOALA_AMD_NO_QUAD'):  # (GRU layers as one launch fused over CU quads,
