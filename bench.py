@@ -66,6 +66,8 @@ def parse_args():
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the other operating points (profiling runs)')
+    ap.add_argument('--no-live-traffic', action='store_true', help='do not run the two rocprofv3 --pmc passes that measure HBM bytes '
+                    'per launch (then the last committed profiles/*_pmc.json is quoted, marked as not measured in this run)')
     ap.add_argument('--library', default=None, help='alternative libpv_koala.so (developer A/B runs)')
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL over xGMI) for real runs; gloo only to test the '
                     'multi-rank code path on a single-GPU box together with KOALA_BENCH_SHARE_GPU=1')
@@ -160,6 +162,54 @@ class BoardSampler(object):
                 'peak_sclk_MHz': self.PEAK_SCLK_MHZ, 'source': 'rocm-smi --showclocks --showpower'}
 
 
+PMC_CLASS = {'analysis_kernel': 'analysis', 'gemm_ws2_kernel<0, 4>': 'gemm_input', 'gru_resident8_kernel': 'gru_recurrent',
+             'synthesis_kernel': 'synthesis', 'gemm_wsr_kernel<2, 2>': 'gemm_head'}
+
+
+def live_traffic(args):
+    """HBM bytes per launch of each class's main kernel, measured NOW: two rocprofv3 passes of this same command (a few steps, no
+    extras), one hardware counter each -- FETCH_SIZE, WRITE_SIZE in KiB, kernel-trace only, as MI355X_MICROARCH.md's
+    HBM section prescribes (separate --pmc passes; FETCH_SIZE doubled: on gfx950 this rocprofv3 reports half of a wide
+    streaming read).  Returns {class: bytes} or None when rocprofv3 is missing or a pass fails (the caller then quotes the
+    committed profile)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    if not shutil.which('rocprofv3'):
+        return None
+    per = {}
+    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+        with tempfile.TemporaryDirectory(dir='/tmp') as d:
+            cmd = ['rocprofv3', '--kernel-trace', '--pmc', ctr, '-d', d, '-o', 'p', '--', sys.executable, os.path.abspath(__file__),
+                   '--steps', '3', '--warmup', '1', '--prime-seconds', '0', '--sustain-seconds', '0', '--no-cpu-baseline', '--no-extra',
+                   '--no-live-traffic', '--streams', str(args.streams), '--frames', str(args.frames), '--precision', args.precision]
+            if args.library:
+                cmd += ['--library', args.library]
+            env = dict(os.environ, TMPDIR='/tmp')
+            for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+                env.pop(k, None)
+            try:
+                r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=240)
+                dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith('.db')]
+                if r.returncode != 0 or not dbs:
+                    return None
+                rows = sqlite3.connect(dbs[0]).execute(
+                    'select kernel_name, sum(value), count(*) from counters_collection where counter_name = ? group by kernel_name',
+                    (ctr,)).fetchall()
+            except Exception:
+                return None
+            for name, total, n in rows:
+                for frag, cls in PMC_CLASS.items():
+                    if frag in name and n:
+                        per.setdefault(cls, {})[ctr] = total / n
+    out = {}
+    for cls, v in per.items():
+        if 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
+            out[cls] = int(2 * v['FETCH_SIZE'] * 1024) + int(v['WRITE_SIZE'] * 1024)
+    return out or None
+
+
 def time_steps(fn, sync, steps, warmup):
     for _ in range(warmup):
         fn()
@@ -198,6 +248,17 @@ def extra_points(args, torch, np, koala_amd, model, kb, x, dx, dy, base, local_r
     dt = time_steps(lambda: kb.process_device(1, d1.data_ptr(), o1.data_ptr()), sync, 300, 30)
     out['streaming_T1'] = {'workload': '%d streams x 1 frame per call, %s, device-resident' % (B, args.precision),
                            'frames_per_s': round(B * 300 / dt, 1), 'ms_per_call': round(dt / 300 * 1e3, 4)}
+
+    # -- the same calling convention with twice the streams on the GPU (two m-tiles' worth of quads per CU in turn: the launch
+    # and weight-prologue costs of a frame step are shared by more streams)
+    k8 = koala_amd.create_batch('bench', 2 * B, 1, args.precision, model_path=model, device=dev, library_path=args.library)
+    k8.set_stream(torch.cuda.current_stream().cuda_stream)
+    d8 = torch.cat([d1, d1])
+    o8 = torch.empty_like(d8)
+    dt = time_steps(lambda: k8.process_device(1, d8.data_ptr(), o8.data_ptr()), sync, 300, 30)
+    k8.delete()
+    out['streaming_T1_2x_streams'] = {'workload': '%d streams x 1 frame per call, %s, device-resident' % (2 * B, args.precision),
+                                      'frames_per_s': round(2 * B * 300 / dt, 1), 'ms_per_call': round(dt / 300 * 1e3, 4)}
 
     # -- host-pointer (PCIe-inclusive) path at the bench size: pageable numpy arrays, then page-locked ones
     y = np.empty_like(x)
@@ -449,25 +510,39 @@ def main():
     # profiles/*_pmc.json; FETCH_SIZE doubled per the gfx950 correction); they cannot be collected inside a timed run.
     # `traffic_commit` is the source revision the counters were collected on: compare it with HEAD to see staleness.
     traffic_meta = {}
-    try:
-        import glob
-        pmc_files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json')))
-        pmc = json.load(open(pmc_files[-1])) if pmc_files else {}
-        wl = pmc.pop('_workload', None)
-        commit = pmc.pop('_commit', None)
-        if wl == {'streams_per_gpu': B, 'frames_per_call': T, 'dtype': args.precision}:
-            traffic_meta = {'traffic_source': os.path.basename(pmc_files[-1]), 'traffic_commit': commit,
-                            'traffic_measured_in_this_run': False}
-            for name in stages:
-                for entry in pmc.values():
-                    if isinstance(entry, dict) and entry.get('class') == name and 'hbm_bytes' in entry:
-                        stages[name]['traffic'] = entry['hbm_bytes']
-                        if stages[name]['bound'] == 'hbm':  # against the bytes the kernel was measured to move
-                            gbs = entry['hbm_bytes'] / (stages[name]['avg_launch_ms'] * 1e-3) / 1e9
-                            stages[name]['traffic_GBps'] = round(gbs, 1)
-                            stages[name]['frac_of_peak_by_traffic'] = round(gbs / HBM_PEAK_GBS, 4)
-    except Exception:
-        pass
+    live = None
+    if rank == 0 and world == 1 and not args.no_extra and not args.no_live_traffic:
+        live = live_traffic(args)
+
+    def quote(name, nbytes):
+        stages[name]['traffic'] = nbytes
+        if stages[name]['bound'] == 'hbm':  # against the bytes the kernel was measured to move
+            gbs = nbytes / (stages[name]['avg_launch_ms'] * 1e-3) / 1e9
+            stages[name]['traffic_GBps'] = round(gbs, 1)
+            stages[name]['frac_of_peak_by_traffic'] = round(gbs / HBM_PEAK_GBS, 4)
+    if live:
+        traffic_meta = {'traffic_source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, two passes of this command (3 steps) '
+                                          'started by this run; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch',
+                        'traffic_measured_in_this_run': True}
+        for name in stages:
+            if name in live:
+                quote(name, live[name])
+    else:
+        try:
+            import glob
+            pmc_files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json')))
+            pmc = json.load(open(pmc_files[-1])) if pmc_files else {}
+            wl = pmc.pop('_workload', None)
+            commit = pmc.pop('_commit', None)
+            if wl == {'streams_per_gpu': B, 'frames_per_call': T, 'dtype': args.precision}:
+                traffic_meta = {'traffic_source': os.path.basename(pmc_files[-1]), 'traffic_commit': commit,
+                                'traffic_measured_in_this_run': False}
+                for name in stages:
+                    for entry in pmc.values():
+                        if isinstance(entry, dict) and entry.get('class') == name and 'hbm_bytes' in entry:
+                            quote(name, entry['hbm_bytes'])
+        except Exception:
+            pass
     roofline = dict(stages[dominant])
     roofline['kernel'] = dominant
     roofline.setdefault('traffic', None)
