@@ -190,9 +190,17 @@ def live_traffic(args):
             for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
                 env.pop(k, None)
             try:
-                r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=240)
+                proc = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                        start_new_session=True)
+                try:
+                    rc = proc.wait(timeout=90)
+                except subprocess.TimeoutExpired:  # the profiler and the bench under it, not only the wrapper
+                    import signal
+                    os.killpg(proc.pid, signal.SIGKILL)
+                    proc.wait()
+                    return None
                 dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith('.db')]
-                if r.returncode != 0 or not dbs:
+                if rc != 0 or not dbs:
                     return None
                 rows = sqlite3.connect(dbs[0]).execute(
                     'select kernel_name, sum(value), count(*) from counters_collection where counter_name = ? group by kernel_name',
