@@ -297,7 +297,7 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     dev_steps_mt_ = dev_int("KOALA_AMD_STEPS_MT", 192);
     // GRU layers as ONE launch fused over CU quads (kns_gruq.hip), bit-identical to the two-kernel form.  Taken for ONE-FRAME
     // calls of large batches (its one-step form, gru_quad1_kernel), where a CU then pulls a quarter of W_ih and W_hh (300 KiB)
-    // per layer instead of a half of one and all of the other (~740 KiB) and a layer is one launch: 171 against 222 us per
+    // per layer instead of a half of one and all of the other (~740 KiB) and a layer is one launch: 128 against 222 us per
     // 4096-stream frame step; a one-step launch has no exchange between workgroups at all.  For multi-frame calls it measured slower (354 against 278 us per layer at
     // 64 frames): there it is an A/B arm of the developer build (KOALA_AMD_QUAD=1; KOALA_AMD_NO_QUAD=1
     // turns it off everywhere).
@@ -704,9 +704,10 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     // 192 m-tiles in bf16 (3 072 streams: 218 vs 264 us per frame step; 512 streams: 113 vs 212; at 4 096 it loses, 256 vs
     // 222) and at every size measured in fp32 (4 096 streams: 628 vs 815 us).  Same arithmetic, bit for bit.
     const int small_env = dev_small_mt_;
-    // (bf16, m-tiles in whole quads: from 112 m-tiles on the one-step quad kernel is faster -- 2 048 streams: 159 against 173 us
-    // per frame step, 4 096: 171 against 222 with the chunked kernels; 1 024: 153 against 132, so the low-latency kernel below)
-    const int small_mt = small_env > 0 ? small_env : (prec_ == kBf16 ? (use_quad_ ? 111 : 192) : 256);
+    // (bf16, m-tiles in whole quads: from 40 m-tiles on the one-step quad kernel is faster -- 768 streams: 116 against 122 us per
+    // frame step, 1 536: 116 against 158, 4 096: 128 against 222 with the chunked kernels; 512: 113 against 112, so the
+    // low-latency kernel below)
+    const int small_mt = small_env > 0 ? small_env : (prec_ == kBf16 ? (use_quad_ ? 39 : 192) : 256);
     const bool small = T == 1 && mtb <= small_mt && !no_small_;
     // Fewer than 256 m-tiles: the chunked recurrent kernels would occupy mtb workgroups, so the layers run frame
     // by frame through the low-latency kernel instead (17 x mtb workgroups of three waves per frame, input GEMM included):

@@ -498,22 +498,29 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad_kernel(GruQuadArgs g
 //
 // One frame per call (T = 1): the same decomposition -- workgroup c of a quad holds the W_ih and W_hh columns of hidden units
 // 64 c .. 64 c + 63 and serves unit tile 16 for m-tile c, so a CU pulls 300 KiB of weights per layer instead of ~740 -- but no
-// recurrence, hence no exchange between workgroups, no rings and no phases: stage everything, two barriers, done.
-//   prologue   unit tile 16's W_ih -> LDS; h_{-1} of the four m-tiles -> four operand images; x of the four m-tiles -> LDS; every
-//              wave its resident weights (h waves 0..2 also one gate of unit tile 16's W_hh: used once, straight into registers)
-//   barrier A
-//   x waves    x . W_ih + b_ih of the four blocks -> fp16 in LDS (wave 3: + unit tile 16's where m = c, kept in registers)
-//   h waves    h . W_hh of the four blocks, accumulators (starting from b_hh) kept in registers (waves 0..2: + one gate of unit
-//              tile 16 where m = c -> LDS)
+// recurrence, hence no exchange between workgroups, no rings and no phases.  A launch is bound by what a CU can pull through its
+// vector-memory path (445 KiB at 64 B per clock: ~7 000 cycles) and by 2 x ~120 MFMAs per SIMD (~4 000), so the two are overlapped:
+//   prologue   requests, in this order: x of the four m-tiles and unit tile 16's W_ih (global -> LDS directly), h_{-1} of the four
+//              m-tiles (fp32 -> four operand images), then the first kQ1Ahead k-blocks of the wave's resident weights
+//   barrier A  (staging complete; weights still streaming in)
+//   k loop     k-block by k-block: request the weights of k-block k + kQ1Ahead, then the MFMAs of k-block k for all four blocks
+//              x waves: x . W_ih (waves 0..2 also one gate of unit tile 16's, m-tile c);  h waves: h . W_hh from b_hh (waves
+//              0..2 also one gate of unit tile 16's)
+//   x waves    + b_ih -> fp16 in LDS
 //   barrier B
 //   h waves    gates of the four blocks -> hidden state (fp32) and hidden sequence (operand words); x wave 3: unit tile 16's
-// Bit for bit the arithmetic of every other bf16 path.
+// Every chain is k-ascending: bit for bit the arithmetic of every other bf16 path.
 constexpr int kQ1OffHs = 0;                            // [4] operand images of h_{-1}
 constexpr int kQ1OffXs = 4 * kQHsBytes;                // [4][NBX] KiB (sized for NBX = 11)
 constexpr int kQ1OffGi = kQ1OffXs + 4 * 11 * 1024;     // [4 blocks][4 pairs][3 gates][64][8 B]
-constexpr int kQ1OffGh16 = kQ1OffGi + 4 * 4 * 1536;    // [3][64][16 B]
-constexpr int kQ1OffW16x = kQ1OffGh16 + 3072;          // [3 gates][NBX] KiB
+constexpr int kQ1OffGh16 = kQ1OffGi + 4 * 4 * 1536;    // [3][64][16 B]: h . W_hh of unit tile 16 (fp32)
+constexpr int kQ1OffGi16 = kQ1OffGh16 + 3072;          // [3][64][8 B]: x . W_ih + b_ih of unit tile 16 (fp16)
+constexpr int kQ1OffW16x = kQ1OffGi16 + 1536;          // [3 gates][NBX] KiB
 constexpr int kQ1Lds = kQ1OffW16x + 3 * 11 * 1024;
+#ifndef Q1_AHEAD
+#define Q1_AHEAD 2
+#endif
+constexpr int kQ1Ahead = Q1_AHEAD;  // k-blocks of weights in flight ahead of the MFMAs (a global load takes ~2 300 cycles, a k-block ~430)
 
 template <int NB0>
 __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad1_kernel(GruQuadArgs g) {
@@ -530,53 +537,59 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad1_kernel(GruQuadArgs 
     const bool even = (lane & 1) == 0;
     const int lane_off = ((lane >> 4) * 4 + (even ? 0 : 2) + 16 * ((colq & ~1) >> 3)) * 16 + ((colq & ~1) & 7) * 2;
     const int j = wave & 3, u = 4 * c + j;
+    // developer stamps (KOALA_AMD_QUAD_DBG=<workgroup>, tools/t1_stamps.py): row [wave][0][0..5] + [wave][1][0]
+    unsigned long long *dbg = (g.dbg && bid == g.dbg_block && lane == 0) ? g.dbg + (size_t) wave * 4 * 8 : nullptr;
+    auto stamp = [&](int slot) {
+        if (dbg) dbg[slot] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
 
-    // ---- resident weights first (the longest loads), then the staging
-    frag_t w[33];   // x waves: W_ih tile u [3 gates][NBX]; h waves: W_hh tile u [9][3 gates]
-    frag_t w16[9];  // h waves 0..2: gate j of unit tile 16's W_hh
-    float b0, b1, b2, b16 = 0.f;
-    if (wave < 4) {
-        const frag_t *wih = (const frag_t *) g.wih;
+    // ---- staging requests (both roles).  x and unit tile 16's W_ih are copied as they are: global -> LDS without passing
+    // registers (a lane's 16 bytes land at the wave-uniform LDS address + 16 lane).
+    constexpr int kXF = (4 * NBX + kQWaves - 1) / kQWaves, kWF = (3 * NBX + kQWaves - 1) / kQWaves;
+    constexpr int kHF = 4 * (kUnitTiles + 1) / kQWaves;  // 4 x 18 tile slots (17 + the zero half of k-block 8) = 9 per wave
+    static_assert(4 * (kUnitTiles + 1) % kQWaves == 0, "whole tiles per wave");
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
 #pragma unroll
-        for (int gt = 0; gt < 3; ++gt)
-#pragma unroll
-            for (int blk = 0; blk < NBX; ++blk) w[gt * NBX + blk] = wih[((size_t) (u * 3 + gt) * NBX + blk) * 64 + lane];
-        b0 = g.bih[(u * 3 + 0) * 16 + colq];
-        b1 = g.bih[(u * 3 + 1) * 16 + colq];
-        b2 = g.bih[(u * 3 + 2) * 16 + colq];
-    } else {
-        const frag_t *whh = (const frag_t *) g.whh;
-#pragma unroll
-        for (int i = 0; i < 27; ++i) w[i] = whh[((size_t) (u * 3 + i % 3) * 9 + i / 3) * 64 + lane];
-        const int g16 = j < 3 ? j : 0;
-#pragma unroll
-        for (int blk = 0; blk < 9; ++blk) w16[blk] = whh[((size_t) (16 * 3 + g16) * 9 + blk) * 64 + lane];
-        b0 = g.bhh[(u * 3 + 0) * 16 + colq];
-        b1 = g.bhh[(u * 3 + 1) * 16 + colq];
-        b2 = g.bhh[(u * 3 + 2) * 16 + colq];
-        b16 = g.bhh[(16 * 3 + g16) * 16 + colq];
-    }
-    for (int i = wave; i < 3 * NBX; i += kQWaves)
-        ((frag_t *) (smem + kQ1OffW16x))[i * 64 + lane] = ((const frag_t *) g.wih)[((size_t) 48 * NBX + i) * 64 + lane];
-    for (int i = tid; i < 4 * kQHsBytes / 16; i += 64 * kQWaves) ((uint4 *) (smem + kQ1OffHs))[i] = uint4{0, 0, 0, 0};
-    for (int i = wave; i < 4 * NBX; i += kQWaves) {
+    for (int q = 0; q < kXF; ++q) {
+        const int i = wave + kQWaves * q;
         const int m = i / NBX, k = i % NBX;
-        const frag_t *src = k < NB0 ? (const frag_t *) g.a0 + ((size_t) (mt0 + m) * NB0 + k) * 64
-                                    : (const frag_t *) g.a1 + ((size_t) (mt0 + m) * 9 + (k - NB0)) * 64;
-        ((frag_t *) (smem + kQ1OffXs))[(m * 11 + k) * 64 + lane] = src[lane];
+        if (i < 4 * NBX)
+            __builtin_amdgcn_global_load_lds(
+                (gptr_t) ((k < NB0 ? (const frag_t *) g.a0 + ((size_t) (mt0 + m) * NB0 + k) * 64
+                                   : (const frag_t *) g.a1 + ((size_t) (mt0 + m) * 9 + (k - NB0)) * 64) + lane),
+                (lptr_t) (smem + kQ1OffXs + (m * 11 + k) * 1024), 16, 0, 0);
     }
-    __syncthreads();  // (the images are zero before the tiles go in: k-block 8's upper half must stay zero)
-    for (int idx = wave; idx < 4 * kUnitTiles; idx += kQWaves) {
-        const int m = idx / kUnitTiles, t = idx % kUnitTiles;
-        const f32x4 hv = ((const f32x4 *) g.hstate_in)[((size_t) (mt0 + m) * kUnitTiles + t) * 64 + lane];
-        unsigned w0, w1;
-        q_pack(hv, even, w0, w1);
-        char *img = smem + kQ1OffHs + m * kQHsBytes + q_tile_off(t) + lane_off;
-        *(unsigned *) img = w0;
-        *(unsigned *) (img + 16) = w1;
+#pragma unroll
+    for (int q = 0; q < kWF; ++q) {
+        const int i = wave + kQWaves * q;
+        if (i < 3 * NBX)
+            __builtin_amdgcn_global_load_lds((gptr_t) ((const frag_t *) g.wih + ((size_t) 48 * NBX + i) * 64 + lane),
+                                             (lptr_t) (smem + kQ1OffW16x + i * 1024), 16, 0, 0);
     }
-    __syncthreads();  // barrier A
-
+    f32x4 sh[kHF];
+#pragma unroll
+    for (int q = 0; q < kHF; ++q) {
+        const int idx = wave + kQWaves * q;
+        const int m = idx / (kUnitTiles + 1), t = idx % (kUnitTiles + 1);
+        // (slot 17 loads tile 16 again and is zeroed when it is used: no branch around a load, see kns_gru.hip)
+        sh[q] = ((const f32x4 *) g.hstate_in)[((size_t) (mt0 + m) * kUnitTiles + (t < kUnitTiles ? t : kUnitTiles - 1)) * 64 + lane];
+    }
+    // staging -> LDS.  The 18 tile slots of an image cover all of its 9 KiB (slot 17 = the zero half of k-block 8).
+    auto images = [&]() {
+#pragma unroll
+        for (int q = 0; q < kHF; ++q) {
+            const int idx = wave + kQWaves * q;
+            const int m = idx / (kUnitTiles + 1), t = idx % (kUnitTiles + 1);
+            unsigned w0, w1;
+            q_pack(sh[q], even, w0, w1);
+            if (t == kUnitTiles) w0 = w1 = 0u;
+            char *img = smem + kQ1OffHs + m * kQHsBytes + q_tile_off(t) + lane_off;
+            *(unsigned *) img = w0;
+            *(unsigned *) (img + 16) = w1;
+        }
+    };
     // one tile of h_0 of m-tile m: fp32 state, operand words of the hidden sequence
     auto emit = [&](int m, int tile, const f32x4 &hnew) {
         ((f32x4 *) g.hstate_out)[((size_t) (mt0 + m) * kUnitTiles + tile) * 64 + lane] = hnew;
@@ -588,83 +601,129 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad1_kernel(GruQuadArgs 
     };
 
     if (wave < 4) {
-        const frag_t(&wx)[3][NBX] = *(const frag_t(*)[3][NBX]) & w[0];
-        u32x2 gi16[3] = {u32x2{0, 0}, u32x2{0, 0}, u32x2{0, 0}};
+        // ---------------------------------------------------------------------------------------- x waves
+        const frag_t *wih = (const frag_t *) g.wih + (size_t) (u * 3) * NBX * 64 + lane;  // [gate][k-block] fragments of tile u
+        frag_t w[3][NBX];
+        auto request = [&](const int blk) {
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt) w[gt][blk] = wih[(gt * NBX + blk) * 64];
+        };
+#pragma unroll
+        for (int blk = 0; blk < kQ1Ahead && blk < NBX; ++blk) request(blk);
+        const float b0 = g.bih[(u * 3 + 0) * 16 + colq], b1 = g.bih[(u * 3 + 1) * 16 + colq], b2 = g.bih[(u * 3 + 2) * 16 + colq];
+        const float b16 = g.bih[(16 * 3 + (j < 3 ? j : 0)) * 16 + colq];
+        f32x4 hp16 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (j == 3) hp16 = ((const f32x4 *) g.hstate_in)[((size_t) (mt0 + c) * kUnitTiles + 16) * 64 + lane];
+        stamp(1);
+        images();
+        stamp(2);
+        __syncthreads();  // barrier A
+        stamp(3);
+        f32x4 acc[4][3], a16 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt) acc[m][gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const frag_t *xs = (const frag_t *) (smem + kQ1OffXs) + lane;
+        const frag_t *w16x = (const frag_t *) (smem + kQ1OffW16x) + (j < 3 ? j : 0) * NBX * 64 + lane;
+#pragma unroll
+        for (int blk = 0; blk < NBX; ++blk) {
+            if (blk + kQ1Ahead < NBX) request(blk + kQ1Ahead);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const frag_t a = xs[(m * 11 + blk) * 64];
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt) acc[m][gt] = PBF16::mma(a, w[gt][blk], acc[m][gt]);
+            }
+            if (j < 3) a16 = PBF16::mma(xs[(c * 11 + blk) * 64], w16x[blk * 64], a16);  // one gate of unit tile 16, m-tile c
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stamp(4);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const frag_t *xa = (const frag_t *) (smem + kQ1OffXs + m * 11 * 1024);
-            f32x4 acc[3];
-#pragma unroll
-            for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            q_x_mma<NBX>(acc, xa, wx, lane);
             char *ring = smem + kQ1OffGi + ((m * 4 + j) * 3) * 512 + lane * 8;
 #pragma unroll
             for (int gt = 0; gt < 3; ++gt) {
                 const float b = gt == 0 ? b0 : gt == 1 ? b1 : b2;
-                f32x4 v = acc[gt];
+                f32x4 v = acc[m][gt];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = v[i] + b;
                 *(f16x4 *) (ring + gt * 512) = PBF16::to_gi(v);
             }
-            if (j == 3 && m == c) {
+        }
+        if (j < 3) {
 #pragma unroll
-                for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                q_x_mma16<NBX>(acc, xa, (const frag_t *) (smem + kQ1OffW16x), lane);
-#pragma unroll
-                for (int gt = 0; gt < 3; ++gt) {
-                    const float b = g.bih[(16 * 3 + gt) * 16 + colq];
-                    f32x4 v = acc[gt];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = v[i] + b;
-                    gi16[gt] = __builtin_bit_cast(u32x2, PBF16::to_gi(v));
-                }
-            }
+            for (int i = 0; i < 4; ++i) a16[i] = a16[i] + b16;
+            *(f16x4 *) (smem + kQ1OffGi16 + j * 512 + lane * 8) = PBF16::to_gi(a16);
         }
         __syncthreads();  // barrier B
+        stamp(5);
         if (j == 3) {  // unit tile 16 of m-tile c
             const char *gh = smem + kQ1OffGh16 + lane * 16;
-            f32x4 acc[3];
-            acc[0] = *(const f32x4 *) gh;
-            acc[1] = *(const f32x4 *) (gh + 1024);
-            acc[2] = *(const f32x4 *) (gh + 2048);
-            const f32x4 h16 = ((const f32x4 *) g.hstate_in)[((size_t) (mt0 + c) * kUnitTiles + 16) * 64 + lane];
-            emit(c, 16, q_gates(acc, gi16[0], gi16[1], gi16[2], h16));
+            f32x4 gacc[3];
+            gacc[0] = *(const f32x4 *) gh;
+            gacc[1] = *(const f32x4 *) (gh + 1024);
+            gacc[2] = *(const f32x4 *) (gh + 2048);
+            const char *gx = smem + kQ1OffGi16 + lane * 8;
+            emit(c, 16, q_gates(gacc, *(const u32x2 *) gx, *(const u32x2 *) (gx + 512), *(const u32x2 *) (gx + 1024), hp16));
         }
+        stamp(8);
         return;
     }
 
-    // ---- h waves
-    const frag_t(&wh)[27] = *(const frag_t(*)[27]) & w[0];
-    f32x4 acc[4][3];
+    // -------------------------------------------------------------------------------------------- h waves
+    const frag_t *whh = (const frag_t *) g.whh + (size_t) (u * 3) * 9 * 64 + lane;  // [gate][k-block] fragments of tile u
+    const frag_t *whh16 = (const frag_t *) g.whh + (size_t) (16 * 3 + (j < 3 ? j : 0)) * 9 * 64 + lane;
+    frag_t w[9][3], w16[9];
+    auto request = [&](const int blk) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        acc[m][0] = f32x4{b0, b0, b0, b0};  // the recurrent chains start from b_hh
+        for (int gt = 0; gt < 3; ++gt) w[blk][gt] = whh[(gt * 9 + blk) * 64];
+        w16[blk] = whh16[blk * 64];  // (used by waves 0..2; requested by all four: no conditional load in the stream)
+    };
+#pragma unroll
+    for (int blk = 0; blk < kQ1Ahead && blk < 9; ++blk) request(blk);
+    const float b0 = g.bhh[(u * 3 + 0) * 16 + colq], b1 = g.bhh[(u * 3 + 1) * 16 + colq], b2 = g.bhh[(u * 3 + 2) * 16 + colq];
+    const float b16 = g.bhh[(16 * 3 + (j < 3 ? j : 0)) * 16 + colq];
+    stamp(1);
+    images();
+    stamp(2);
+    __syncthreads();  // barrier A
+    stamp(3);
+    f32x4 acc[4][3], a16 = f32x4{b16, b16, b16, b16};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {  // the recurrent chains start from b_hh
+        acc[m][0] = f32x4{b0, b0, b0, b0};
         acc[m][1] = f32x4{b1, b1, b1, b1};
         acc[m][2] = f32x4{b2, b2, b2, b2};
-        const frag_t *ha = (const frag_t *) (smem + kQ1OffHs + m * kQHsBytes);
-        if (m == c && j < 3) {  // one gate of unit tile 16 rides along (its weights are in registers: plain chain here)
-            f32x4 a16 = f32x4{b16, b16, b16, b16};
-#pragma unroll
-            for (int blk = 0; blk < 9; ++blk) {
-                const frag_t a = ha[blk * 64 + lane];
-#pragma unroll
-                for (int gt = 0; gt < 3; ++gt) acc[m][gt] = PBF16::mma(a, wh[blk * 3 + gt], acc[m][gt]);
-                a16 = PBF16::mma(a, w16[blk], a16);
-            }
-            *(f32x4 *) (smem + kQ1OffGh16 + j * 1024 + lane * 16) = a16;
-        } else {
-            f32x4 dummy = f32x4{0.f, 0.f, 0.f, 0.f};
-            q_h_mma<false>(acc[m], dummy, ha, wh, (const frag_t *) nullptr, lane);
-        }
     }
+    const frag_t *hs = (const frag_t *) (smem + kQ1OffHs) + lane;
+#pragma unroll
+    for (int blk = 0; blk < 9; ++blk) {
+        if (blk + kQ1Ahead < 9) request(blk + kQ1Ahead);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const frag_t a = hs[(m * 9 + blk) * 64];
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt) acc[m][gt] = PBF16::mma(a, w[blk][gt], acc[m][gt]);
+        }
+        if (j < 3) a16 = PBF16::mma(hs[(c * 9 + blk) * 64], w16[blk], a16);  // one gate of unit tile 16, m-tile c
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (j < 3) *(f32x4 *) (smem + kQ1OffGh16 + j * 1024 + lane * 16) = a16;
+    // the previous state of the tiles this wave finishes: requested here, behind the weights
+    f32x4 hp[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) hp[m] = ((const f32x4 *) g.hstate_in)[((size_t) (mt0 + m) * kUnitTiles + u) * 64 + lane];
+    stamp(4);
     __syncthreads();  // barrier B
+    stamp(5);
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const char *ring = smem + kQ1OffGi + ((m * 4 + j) * 3) * 512 + lane * 8;
         const u32x2 pr = *(const u32x2 *) ring, pz = *(const u32x2 *) (ring + 512), pn = *(const u32x2 *) (ring + 1024);
-        const f32x4 hprev = ((const f32x4 *) g.hstate_in)[((size_t) (mt0 + m) * kUnitTiles + u) * 64 + lane];
-        emit(m, u, q_gates(acc[m], pr, pz, pn, hprev));
+        emit(m, u, q_gates(acc[m], pr, pz, pn, hp[m]));
     }
+    stamp(8);
 }
 
 bool gru_quad_supported(int precision, int mtiles, int nb0) {

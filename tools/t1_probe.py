@@ -18,10 +18,13 @@ def main():
     model = params.ensure_params(os.path.join(ROOT, 'build', 'random_1234.kns'), 'random', 1234)
     dev = any(k.startswith('KOALA_AMD_') and k != 'KOALA_AMD_PRECISION' for k in os.environ)
     lib = koala_amd.developer_library_path() if dev else None
-    for B in (512, 1024, 1776, 1792, 2048, 3072, 4096, 8192):
+    if os.environ.get('T1_LIB'):  # a variant library (tools/variant_lib.sh)
+        lib = os.path.abspath(os.environ['T1_LIB'])
+    sizes = [int(v) for v in os.environ.get('T1_SIZES', '512,1024,1776,1792,2048,3072,4096,8192').split(',')]
+    for B in sizes:
         x = torch.from_numpy(np.tile(synth_streams(64, 1, 1), (B // 64 + 1, 1))[:B].copy()).cuda()
         y = torch.empty_like(x)
-        for prec in ('bf16', 'fp32'):
+        for prec in os.environ.get('T1_PRECISIONS', 'bf16,fp32').split(','):
             kb = koala_amd.create_batch('k', B, 1, prec, model_path=model, library_path=lib)
             kb.set_stream(torch.cuda.current_stream().cuda_stream)
             for _ in range(50):
