@@ -17,22 +17,45 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     constexpr bool kSigmoid = (OUT == kOutMask || OUT == kOutASigmoid);
     constexpr int NU = kApack ? P::NPB : 1;  // n-tiles per unit of work
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb = g.nb0 + g.taps * g.nb1;
     const int mt0 = blockIdx.x * kGemmMT;
     const int mcount = min(kGemmMT, g.mtiles - mt0);
 
-    // stage the A tile in LDS, keeping fragment order: [m-tile][k-block][lane] 16-byte words
+    const int units = g.ntiles / NU;
+    const int units_per_y = ceil_div(units, (int) gridDim.y);
+    const int u_begin = blockIdx.y * units_per_y;
+    const int u_end = min(units, u_begin + units_per_y);
+    const frag_t *w = (const frag_t *) g.w;
+    // The weights of the wave's first unit are requested BEFORE the A tile is staged and the A tile goes global -> LDS directly:
+    // one memory round trip in front of the first MFMA instead of two (one-frame calls are made of these: 7.8-8.9 us per launch
+    // with the staging loop and the weight queue one after the other).
+    frag_t bq[kPF][NU];
+    auto prefetch = [&](int u) {
+#pragma unroll
+        for (int p = 0; p < kPF; ++p)
+            if (p < nb)
+#pragma unroll
+                for (int j = 0; j < NU; ++j) bq[p][j] = w[((size_t) (u * NU + j) * nb + p) * 64 + lane];
+    };
+    const int u_first = u_begin + wave;
+    if (u_first < u_end) prefetch(u_first);
+
+    // stage the A tile in LDS, keeping fragment order: [m-tile][k-block][lane] 16-byte words (a wave copies 1 KiB per request:
+    // a lane's 16 bytes land at the wave-uniform LDS address + 16 lane)
     uint4 *lds_a = (uint4 *) smem;
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    auto copy_in = [&](const uint4 *src, uint4 *dst, int kib) {
+        for (int ch = wave; ch < kib; ch += 4)
+            __builtin_amdgcn_global_load_lds((gptr_t) (src + ch * 64 + lane), (lptr_t) (dst + ch * 64), 16, 0, 0);
+    };
     for (int m = 0; m < mcount; ++m) {
-        if (g.nb0) {
-            const uint4 *src = (const uint4 *) g.a0 + (size_t) (mt0 + m) * g.nb0 * 64;
-            for (int i = tid; i < g.nb0 * 64; i += 256) lds_a[m * nb * 64 + i] = src[i];
-        }
-        for (int tap = 0; tap < g.taps; ++tap) {
-            const uint4 *src1 = (const uint4 *) ((const char *) g.a1 + tap * g.tap_stride) + (size_t) (mt0 + m) * g.nb1 * 64;
-            for (int i = tid; i < g.nb1 * 64; i += 256) lds_a[(m * nb + g.nb0 + tap * g.nb1) * 64 + i] = src1[i];
-        }
+        if (g.nb0) copy_in((const uint4 *) g.a0 + (size_t) (mt0 + m) * g.nb0 * 64, lds_a + m * nb * 64, g.nb0);
+        for (int tap = 0; tap < g.taps; ++tap)
+            copy_in((const uint4 *) ((const char *) g.a1 + tap * g.tap_stride) + (size_t) (mt0 + m) * g.nb1 * 64,
+                    lds_a + (m * nb + g.nb0 + tap * g.nb1) * 64, g.nb1);
     }
     for (int m = mcount; m < kGemmMT; ++m)
         for (int i = tid; i < nb * 64; i += 256) lds_a[m * nb * 64 + i] = uint4{0, 0, 0, 0};
@@ -41,13 +64,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const frag_t *lds_f = (const frag_t *) smem;
     char *scratch = smem + (size_t) kGemmMT * nb * 1024 + (size_t) wave * kGemmMT * 1024;  // per-wave transposer
 
-    const int units = g.ntiles / NU;
-    const int units_per_y = ceil_div(units, (int) gridDim.y);
-    const int u_begin = blockIdx.y * units_per_y;
-    const int u_end = min(units, u_begin + units_per_y);
-    const frag_t *w = (const frag_t *) g.w;
-
-    for (int u = u_begin + wave; u < u_end; u += 4) {
+    for (int u = u_first; u < u_end; u += 4) {
         const int nt0 = u * NU;
         f32x4 acc[NU][kGemmMT];
 #pragma unroll
@@ -55,12 +72,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int m = 0; m < kGemmMT; ++m) acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        frag_t bq[kPF][NU];
-#pragma unroll
-        for (int p = 0; p < kPF; ++p)
-            if (p < nb)
-#pragma unroll
-                for (int j = 0; j < NU; ++j) bq[p][j] = w[((size_t) (nt0 + j) * nb + p) * 64 + lane];
+        if (u != u_first) prefetch(u);
         for (int blk0 = 0; blk0 < nb; blk0 += kPF) {
 #pragma unroll
             for (int p = 0; p < kPF; ++p) {
