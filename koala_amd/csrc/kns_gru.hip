@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64 * W, W / 4) void gru_kernel(GruArgs g) {
 // ---- low-latency GRU layer: input GEMM + recurrent GEMM + gates of one frame, one wavefront per (unit tile, m-tile).
 // Arithmetic is, operation for operation, what the chunked path does (same MFMA, same k order, gi rounded to its storage
 // type before the gates, same gate formulas per precision), so a stream's samples do not depend on which path ran.
-template <class P>
+template <class P, int NB0>  // NB0: k-blocks of the y part of the layer input (everything static: no branch around a load or an MFMA)
 __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
     // One workgroup per (unit tile, m-tile), one wave per gate: each wave streams only its gate's weights (a third of the
     // tile's), eight k-blocks of operands requested before the MFMAs that use them; the three accumulator pairs meet
@@ -142,62 +142,66 @@ __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
     typedef typename P::elem_t elem_t;
     constexpr int NBH = P::NBH;
     __shared__ __attribute__((aligned(16))) char hbuf[NBH * 1024];
+    __shared__ __attribute__((aligned(16))) char hspare[1024];
     __shared__ f32x4 xch[2][3][64];  // [input | recurrent][gate][lane]
     const int lane = threadIdx.x & 63;
     const int gt = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // this wave's gate: r, z, n
     const int u = blockIdx.x, mt = blockIdx.y;
     const int colq = lane & 15, rowq = (lane >> 4) * 4;
-    const int nb = g.nb0 + NBH;
+    constexpr int nb = NB0 + NBH;
 
-    // h_{t-1}: fp32 C-fragments -> operand-typed A-fragments through LDS (the 17 tiles shared out over the three waves)
-    for (int i = threadIdx.x; i < NBH * 64; i += 192) ((uint4 *) hbuf)[i] = uint4{0, 0, 0, 0};
-    __syncthreads();
+    // Everything the wave needs from memory is requested before anything is waited for -- h_{t-1}, the operand blocks, this
+    // gate's W_ih and W_hh fragments, the biases: ONE memory round trip per launch (with the staging of h, the two weight queues
+    // and the biases one after the other it was five, and a one-frame call is fifteen such launches).
+    constexpr int kHT = (kUnitTiles + 2) / 3;  // tiles of h_{t-1} this wave converts
     const f32x4 hown = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u) * 64 + lane];
-    for (int v = gt; v < kUnitTiles; v += 3) {
-        const f32x4 hv = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + v) * 64 + lane];
-        const int k = v * 16 + colq;
-        elem_t *dst = (elem_t *) hbuf + (k / P::KB) * 64 * P::EPL;
+    f32x4 hv[kHT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dst[P::off(rowq + i, k % P::KB)] = P::cvt(hv[i]);
+    for (int q = 0; q < kHT; ++q) {
+        const int v = gt + 3 * q;
+        hv[q] = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + (v < kUnitTiles ? v : kUnitTiles - 1)) * 64 + lane];
     }
-
     const frag_t *wih = (const frag_t *) g.wih + (size_t) (u * 3 + gt) * nb * 64 + lane;
     const frag_t *whh = (const frag_t *) g.whh + (size_t) (u * 3 + gt) * NBH * 64 + lane;
-    const frag_t *a0 = (const frag_t *) g.a0 + (size_t) mt * g.nb0 * 64 + lane;
+    const frag_t *a0 = (const frag_t *) g.a0 + (size_t) mt * NB0 * 64 + lane;
     const frag_t *a1 = (const frag_t *) g.a1 + (size_t) mt * NBH * 64 + lane;
+    frag_t xa[nb], wi[nb], wh[NBH];
+#pragma unroll
+    for (int p = 0; p < nb; ++p) {
+        xa[p] = p < NB0 ? a0[(size_t) p * 64] : a1[(size_t) (p - NB0) * 64];
+        wi[p] = wih[(size_t) p * 64];
+    }
+#pragma unroll
+    for (int p = 0; p < NBH; ++p) wh[p] = whh[(size_t) p * 64];
+    const float bi = g.bih[(u * 3 + gt) * 16 + colq];
+    const float bh = g.bhh[(u * 3 + gt) * 16 + colq];
+    const float br = g.bhh[(u * 3 + 0) * 16 + colq], bz = g.bhh[(u * 3 + 1) * 16 + colq], bn = g.bhh[(u * 3 + 2) * 16 + colq];
+    __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks the loads to their uses to save registers: five round trips again)
+
+    // h_{t-1}: fp32 C-fragments -> operand-typed A-fragments in LDS (the 17 tiles shared out over the three waves; the columns
+    // past tile 16 -- the upper half of the bf16 layout's last k-block -- are written as zeros by the wave that has a slot free)
+#pragma unroll
+    for (int q = 0; q < kHT; ++q) {  // (no branch: a slot past the image -- fp32 layout, tile 17 -- writes into a spare block instead)
+        const int v = gt + 3 * q;
+        const int k = v * 16 + colq;
+        elem_t *dst = v * 16 < NBH * P::KB ? (elem_t *) hbuf + (k / P::KB) * 64 * P::EPL : (elem_t *) hspare;
+        const uint32_t keep = v < kUnitTiles ? 0xffffffffu : 0u;  // (a mask, not a branch: slot 17 is the zero tile)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[P::off(rowq + i, k % P::KB)] = P::cvt(u2f(f2u(hv[q][i]) & keep));
+    }
+    static_assert(3 * kHT * 16 >= NBH * P::KB, "the three waves' tile slots cover the operand image");
+
     f32x4 acci = f32x4{0.f, 0.f, 0.f, 0.f}, acch = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (P::kPrec == kBf16) {  // bf16 configuration: this gate's recurrent chain starts from its b_hh
-        const float bh = g.bhh[(u * 3 + gt) * 16 + colq];
-        acch = f32x4{bh, bh, bh, bh};
-    }
-    constexpr int kAhead = 8;
-    for (int b0 = 0; b0 < nb; b0 += kAhead) {
-        frag_t a[kAhead], w[kAhead];
+    if (P::kPrec == kBf16) acch = f32x4{bh, bh, bh, bh};  // bf16 configuration: this gate's recurrent chain starts from its b_hh
 #pragma unroll
-        for (int p = 0; p < kAhead; ++p) {
-            const int blk = b0 + p < nb ? b0 + p : nb - 1;
-            a[p] = blk < g.nb0 ? a0[(size_t) blk * 64] : a1[(size_t) (blk - g.nb0) * 64];
-            w[p] = wih[(size_t) blk * 64];
-        }
-#pragma unroll
-        for (int p = 0; p < kAhead; ++p)
-            if (b0 + p < nb) acci = P::mma(a[p], w[p], acci);
-    }
+    for (int p = 0; p < nb; ++p) acci = P::mma(xa[p], wi[p], acci);
     __syncthreads();  // hbuf complete
 #pragma unroll
-    for (int b0 = 0; b0 < NBH; b0 += kAhead) {
-        frag_t w[kAhead];
-#pragma unroll
-        for (int p = 0; p < kAhead; ++p) w[p] = whh[(size_t) (b0 + p < NBH ? b0 + p : NBH - 1) * 64];
-#pragma unroll
-        for (int p = 0; p < kAhead; ++p)
-            if (b0 + p < NBH) acch = P::mma(((const frag_t *) hbuf)[(b0 + p) * 64 + lane], w[p], acch);
-    }
+    for (int p = 0; p < NBH; ++p) acch = P::mma(((const frag_t *) hbuf)[p * 64 + lane], wh[p], acch);
     {
-        const float b = g.bih[(u * 3 + gt) * 16 + colq];
         f32x4 v = acci;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = v[i] + b;
+        for (int i = 0; i < 4; ++i) v[i] = v[i] + bi;
         xch[0][gt][lane] = P::from_gi(P::to_gi(v));
         xch[1][gt][lane] = acch;
     }
@@ -209,8 +213,6 @@ __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
         gin[q] = xch[0][q][lane];
         gh[q] = xch[1][q][lane];
     }
-    const float br = g.bhh[(u * 3 + 0) * 16 + colq], bz = g.bhh[(u * 3 + 1) * 16 + colq],
-                bn = g.bhh[(u * 3 + 2) * 16 + colq];
     f32x4 hnew;
     if (P::kPrec == kBf16) {
 #pragma unroll
@@ -233,10 +235,21 @@ __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
 
 void launch_gru_small(const GruSmallArgs &a, hipStream_t s) {
     dim3 grid(kUnitTiles, a.mtiles);
-    if (a.precision == kBf16)
-        hipLaunchKernelGGL(gru_small_kernel<PBF16>, grid, dim3(192), 0, s, a);
-    else
-        hipLaunchKernelGGL(gru_small_kernel<PF32>, grid, dim3(192), 0, s, a);
+    auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(192), 0, s, a); };
+    if (a.precision == kBf16) {
+        switch (a.nb0) {
+            case 0: go(gru_small_kernel<PBF16, 0>); break;
+            case 1: go(gru_small_kernel<PBF16, 1>); break;
+            default: go(gru_small_kernel<PBF16, 2>); break;
+        }
+    } else {
+        switch (a.nb0) {
+            case 0: go(gru_small_kernel<PF32, 0>); break;
+            case 1: go(gru_small_kernel<PF32, 1>); break;
+            case 2: go(gru_small_kernel<PF32, 2>); break;
+            default: go(gru_small_kernel<PF32, 3>); break;
+        }
+    }
 }
 
 // ---- 8-wave form of the resident recurrent kernel.  Measured on MI355X: a single wave per SIMD executes its MFMAs and
