@@ -331,25 +331,53 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     // outstanding global load of the wave (s_waitcnt vmcnt(0)) first
     const unsigned flag16 = (unsigned) (uintptr_t) (smem + kR8Lds + 3 * 1024);  // [3 gates]: step count of acc16's content
 
-    // ---- prologue
+    // ---- prologue: everything is requested before anything is waited for (one memory round trip per launch; with the LDS-resident
+    // fragments, the biases, the state and the first pre-activations fetched one group after the other it was eight).  The
+    // fragments that live in LDS go there directly (global -> LDS, a lane's 16 bytes at the wave-uniform address + 16 lane).
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    frag_t *wl1w = wl1 + wave * kR8LdsFrags1 * 64;
+#pragma unroll
+    for (int i = kR8RegFrags1; i < 27; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t) (whh + ((size_t) (u1 * 3 + i % 3) * NBH + i / 3) * 64 + lane),
+                                         (lptr_t) (wl1w + (i - kR8RegFrags1) * 64), 16, 0, 0);
+    for (int i = wave; i < 27; i += kR8Waves)
+        __builtin_amdgcn_global_load_lds((gptr_t) (whh + ((size_t) (u2 * 3 + i % 3) * NBH + i / 3) * 64 + lane),
+                                         (lptr_t) (wl16 + i * 64), 16, 0, 0);
     frag_t w0[27], w1[kR8RegFrags1];
 #pragma unroll
     for (int i = 0; i < 27; ++i) w0[i] = whh[((size_t) (u0 * 3 + i % 3) * NBH + i / 3) * 64 + lane];
 #pragma unroll
     for (int i = 0; i < kR8RegFrags1; ++i) w1[i] = whh[((size_t) (u1 * 3 + i % 3) * NBH + i / 3) * 64 + lane];
-    frag_t *wl1w = wl1 + wave * kR8LdsFrags1 * 64;
-    for (int i = kR8RegFrags1; i < 27; ++i)
-        wl1w[(i - kR8RegFrags1) * 64 + lane] = whh[((size_t) (u1 * 3 + i % 3) * NBH + i / 3) * 64 + lane];
-    for (int i = wave; i < 27; i += kR8Waves) wl16[i * 64 + lane] = whh[((size_t) (u2 * 3 + i % 3) * NBH + i / 3) * 64 + lane];
-    for (int i = tid; i < kGateTiles * 16; i += 64 * kR8Waves) lbias[i] = g.bhh[i];
-
+    constexpr int kBiasPer = (kGateTiles * 16 + 64 * kR8Waves - 1) / (64 * kR8Waves);
+    float bias_in[kBiasPer];
+#pragma unroll
+    for (int q = 0; q < kBiasPer; ++q) {
+        const int i = tid + 64 * kR8Waves * q;
+        bias_in[q] = g.bhh[i < kGateTiles * 16 ? i : kGateTiles * 16 - 1];
+    }
     f32x4 hreg[2];
     hreg[0] = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u0) * 64 + lane];
     hreg[1] = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u1) * 64 + lane];
     const int e16 = q16 ? wave : 0;  // element of the f32x4 this wave owns in tile 16
     float h16 = g.hstate_in[(((size_t) mt * kUnitTiles + u2) * 64 + lane) * 4 + e16];
+    P::gi_t gi[2][3], gi16[3];
+    {
+        const P::gi_t *gp = (const P::gi_t *) g.gi + (size_t) mt * kGateTiles * 64;
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt) {
+            gi[0][gt] = gp[(u0 * 3 + gt) * 64 + lane];
+            gi[1][gt] = gp[(u1 * 3 + gt) * 64 + lane];
+            gi16[gt] = gp[(u2 * 3 + gt) * 64 + lane];
+        }
+    }
     for (int i = tid; i < 2 * NBH * 64; i += 64 * kR8Waves) ((uint4 *) smem)[i] = uint4{0, 0, 0, 0};
     if (tid < 4) ((int *) (smem + kR8Lds + 3 * 1024))[tid] = 0;
+#pragma unroll
+    for (int q = 0; q < kBiasPer; ++q) {
+        const int i = tid + 64 * kR8Waves * q;
+        if (i < kGateTiles * 16) lbias[i] = bias_in[q];
+    }
     __syncthreads();
     auto put_h = [&](char *buf, int u, const f32x4 &h) {
         const int k = u * 16 + colq;
@@ -369,17 +397,6 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     put_h(hbuf0, u0, hreg[0]);
     put_h(hbuf0, u1, hreg[1]);
     if (q16) put_h16(hbuf0, h16);
-
-    P::gi_t gi[2][3], gi16[3];
-    {
-        const P::gi_t *gp = (const P::gi_t *) g.gi + (size_t) mt * kGateTiles * 64;
-#pragma unroll
-        for (int gt = 0; gt < 3; ++gt) {
-            gi[0][gt] = gp[(u0 * 3 + gt) * 64 + lane];
-            gi[1][gt] = gp[(u1 * 3 + gt) * 64 + lane];
-            gi16[gt] = gp[(u2 * 3 + gt) * 64 + lane];
-        }
-    }
     __syncthreads();
 
     // Every wave issues the same vector-memory operations every step and none of them sits inside a branch (the hidden
