@@ -303,6 +303,7 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     // turns it off everywhere).
     quad_all_ = dev_env("KOALA_AMD_QUAD") != nullptr;
     use_quad_ = dev_env("KOALA_AMD_NO_QUAD") == nullptr;
+    fuse_head_ = dev_env("KOALA_AMD_NO_HEAD_FUSE") == nullptr;  // A/B arm: narrow heads as launches of their own in one-frame calls
     quad_nb0_max_ = dev_int("KOALA_AMD_QUAD_NB0MAX", 2);
     qdbg_block_ = dev_int("KOALA_AMD_QUAD_DBG", -1);
     // host-pointer calls are cut into sub-chunks of host_chunk_ frames (two staging slots = the Tmax-sized buffers)
@@ -744,8 +745,14 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     // bit for bit (tests/test_gpu_parity.py::test_alternative_kernels_give_identical_pcm).
     const bool quad = use_quad_ && !small && !small_steps && (T == 1 || (quad_all_ && T < 4096));
     auto gru_quad = [&](const void *a0, int nb0, const void *a1, const void *wih, const float *bih, const void *whh,
-                        const float *bhh, int layer, void *hseq) {
+                        const float *bhh, int layer, void *hseq, const StageDev *head = nullptr) {
         GruQuadArgs g;
+        if (head) {  // the narrow head of the stage before, inside this launch (one-frame calls)
+            g.yh = d_hseq_b_;
+            g.yw = head->w_head;
+            g.yb = head->b_head;
+            g.yvalid = head->head_dim;
+        }
         g.a0 = a0;
         g.a1 = a1;
         g.wih = wih;
@@ -775,6 +782,9 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     if (taps_ > 1)  // the last taps - 1 frames of [context | call] are the next call's context
         (void) hipMemcpyAsync(d_fhist_, (char *) d_feat_ + (size_t) T * feat_frame_bytes_, (size_t) (taps_ - 1) * feat_frame_bytes_,
                               hipMemcpyDeviceToDevice, stream_);
+    // One-frame calls through the quad kernel: the narrow head of stage s (271 -> 1, 5, 40) is computed inside stage s + 1's first
+    // layer launch instead of in a launch of its own (kns_gruq.hip, kHead): 15 launches per frame step become 12.
+    bool head_in_next = false;  // stage s - 1's head has been left to this stage's first layer
     for (int s = 0; s < kStages; ++s) {
         const StageDev &d = sd_[s];
         const void *yprev = s ? d_y_[s - 1] : nullptr;
@@ -788,7 +798,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
                 gru_small(nullptr, 0, d_hseq_a_, d.w_ih_b, d.b_ih_b, d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_, t);
         } else {
             if (quad && nby <= quad_nb0_max_) {
-                gru_quad(yprev, nby, d_e_, d.w_ih_a, d.b_ih_a, d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_);
+                gru_quad(yprev, nby, d_e_, d.w_ih_a, d.b_ih_a, d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_, head_in_next ? &sd_[s - 1] : nullptr);
             } else {
                 gemm(kClsGemmIn, yprev, nby, d_e_, nbh_, d.w_ih_a, d.b_ih_a, d_gi_, kGateTiles, 3 * kHidden, kOutGi);
                 gru(d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_);
@@ -800,7 +810,11 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
                 gru(d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_);
             }
         }
-        if (s < kStages - 1)
+        head_in_next = s < kStages - 1 && quad && T == 1 && fuse_head_ && nby_[s] >= 1 && nby_[s] <= quad_nb0_max_ &&
+                       d.head_tiles == 2 * nby_[s] && !debug_taps_;
+        if (head_in_next)
+            ;
+        else if (s < kStages - 1)
             gemm(kClsGemmHead, nullptr, 0, d_hseq_b_, nbh_, d.w_head, d.b_head, d_y_[s], d.head_tiles, d.head_dim,
                  kOutASigmoid);
         else

@@ -512,20 +512,24 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad_kernel(GruQuadArgs g
 // Every chain is k-ascending: bit for bit the arithmetic of every other bf16 path.
 constexpr int kQ1OffHs = 0;                            // [4] operand images of h_{-1}
 constexpr int kQ1OffXs = 4 * kQHsBytes;                // [4][NBX] KiB (sized for NBX = 11)
-constexpr int kQ1OffGi = kQ1OffXs + 4 * 11 * 1024;     // [4 blocks][4 pairs][3 gates][64][8 B]
+constexpr int kQ1OffW16x = kQ1OffXs + 4 * 11 * 1024;   // [3 gates][NBX] KiB
+constexpr int kQ1OffGi = kQ1OffW16x + 3 * 11 * 1024;   // [4 blocks][4 pairs][3 gates][64][8 B]
 constexpr int kQ1OffGh16 = kQ1OffGi + 4 * 4 * 1536;    // [3][64][16 B]: h . W_hh of unit tile 16 (fp32)
-constexpr int kQ1OffGi16 = kQ1OffGh16 + 3072;          // [3][64][8 B]: x . W_ih + b_ih of unit tile 16 (fp16)
-constexpr int kQ1OffW16x = kQ1OffGi16 + 1536;          // [3 gates][NBX] KiB
-constexpr int kQ1Lds = kQ1OffW16x + 3 * 11 * 1024;
+constexpr int kQ1OffGi16 = kQ1OffGh16 + 3072;          // [3][64][8 B]: x . W_ih + b_ih of unit tile 16 (fp32 -> fp16)
+// (kHead) the previous stage's layer-B hidden images [4][9] KiB are staged where the pre-activations go later
+constexpr int kQ1OffYh = kQ1OffGi;
+constexpr int kQ1Lds = kQ1OffYh + 4 * kQHsBytes;
+static_assert(kQ1OffGi16 + 1536 <= kQ1Lds && kQ1Lds <= 160 * 1024, "LDS");
 #ifndef Q1_AHEAD
 #define Q1_AHEAD 2
 #endif
 constexpr int kQ1Ahead = Q1_AHEAD;  // k-blocks of weights in flight ahead of the MFMAs (a global load takes ~2 300 cycles, a k-block ~430)
 
-template <int NB0>
+template <int NB0, bool kHead>  // kHead: the y part of x is computed here (the previous stage's narrow head), not read
 __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad1_kernel(GruQuadArgs g) {
     typedef bf16x8 frag_t;
     constexpr int NBX = 9 + NB0;
+    static_assert(!kHead || NB0 > 0, "a head feeds a y part");
     __shared__ __attribute__((aligned(16))) char smem[kQ1Lds];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -551,11 +555,29 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad1_kernel(GruQuadArgs 
     static_assert(4 * (kUnitTiles + 1) % kQWaves == 0, "whole tiles per wave");
     typedef const __attribute__((address_space(1))) void *gptr_t;
     typedef __attribute__((address_space(3))) void *lptr_t;
+    // (kHead) the narrow head's operands first: the four hidden images of the previous stage's layer B -> LDS, and per wave the
+    // weights of its chains -- 4 m-tiles x 2 NB0 n-tiles = 8 or 16 chains of 9 MFMAs over the 8 waves: chain ch = wave + 8 q is
+    // (m-tile ch & 3, n-tile ch >> 2)
+    constexpr int kCh = kHead ? NB0 : 1;
+    frag_t yw[kCh][9];
+    float ybias[kCh];
+    if (kHead) {
+        for (int i = wave; i < 4 * 9; i += kQWaves)
+            __builtin_amdgcn_global_load_lds((gptr_t) ((const frag_t *) g.yh + ((size_t) (mt0 + i / 9) * 9 + i % 9) * 64 + lane),
+                                             (lptr_t) (smem + kQ1OffYh + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < kCh; ++q) {
+            const int nt = (wave + kQWaves * q) >> 2;
+#pragma unroll
+            for (int blk = 0; blk < 9; ++blk) yw[q][blk] = ((const frag_t *) g.yw)[((size_t) nt * 9 + blk) * 64 + lane];
+            ybias[q] = g.yb[nt * 16 + colq];
+        }
+    }
 #pragma unroll
     for (int q = 0; q < kXF; ++q) {
         const int i = wave + kQWaves * q;
         const int m = i / NBX, k = i % NBX;
-        if (i < 4 * NBX)
+        if (i < 4 * NBX && !(kHead && k < NB0))
             __builtin_amdgcn_global_load_lds(
                 (gptr_t) ((k < NB0 ? (const frag_t *) g.a0 + ((size_t) (mt0 + m) * NB0 + k) * 64
                                    : (const frag_t *) g.a1 + ((size_t) (mt0 + m) * 9 + (k - NB0)) * 64) + lane),
@@ -590,6 +612,27 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad1_kernel(GruQuadArgs 
             *(unsigned *) (img + 16) = w1;
         }
     };
+    // (kHead) y_prev = sigmoid(h_B . W_head + b_head), columns >= yvalid zero, rounded to the operand type: what gemm_head_kernel /
+    // gemm_kernel<kOutASigmoid> store, written into the staged x operand instead (k-block nt / 2 of m-tile m, column half nt & 1)
+    auto head = [&]() {
+        if (!kHead) return;
+        __syncthreads();  // the hidden images are in LDS (every wave's requests)
+#pragma unroll
+        for (int q = 0; q < kCh; ++q) {
+            const int ch = wave + kQWaves * q, m = ch & 3, nt = ch >> 2;
+            const frag_t *ya = (const frag_t *) (smem + kQ1OffYh + m * kQHsBytes) + lane;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int blk = 0; blk < 9; ++blk) acc = PBF16::mma(ya[blk * 64], yw[q][blk], acc);
+            uint16_t *sc = (uint16_t *) (smem + kQ1OffXs + (m * 11 + (nt >> 1)) * 1024);
+            const bool pad = nt * 16 + colq >= g.yvalid;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float x = pad ? 0.0f : head_sigmoid<PBF16>(acc[i] + ybias[q]);
+                sc[PBF16::off((lane >> 4) * 4 + i, (nt & 1) * 16 + colq)] = PBF16::cvt(x);
+            }
+        }
+    };
     // one tile of h_0 of m-tile m: fp32 state, operand words of the hidden sequence
     auto emit = [&](int m, int tile, const f32x4 &hnew) {
         ((f32x4 *) g.hstate_out)[((size_t) (mt0 + m) * kUnitTiles + tile) * 64 + lane] = hnew;
@@ -615,6 +658,7 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad1_kernel(GruQuadArgs 
         f32x4 hp16 = f32x4{0.f, 0.f, 0.f, 0.f};
         if (j == 3) hp16 = ((const f32x4 *) g.hstate_in)[((size_t) (mt0 + c) * kUnitTiles + 16) * 64 + lane];
         stamp(1);
+        head();
         images();
         stamp(2);
         __syncthreads();  // barrier A
@@ -685,6 +729,7 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad1_kernel(GruQuadArgs 
     const float b0 = g.bhh[(u * 3 + 0) * 16 + colq], b1 = g.bhh[(u * 3 + 1) * 16 + colq], b2 = g.bhh[(u * 3 + 2) * 16 + colq];
     const float b16 = g.bhh[(16 * 3 + (j < 3 ? j : 0)) * 16 + colq];
     stamp(1);
+    head();
     images();
     stamp(2);
     __syncthreads();  // barrier A
@@ -738,12 +783,17 @@ void launch_gru_quad(const GruQuadArgs &a, hipStream_t s) {
         const int n = nquads - q0 < 64 ? nquads - q0 : 64;
         const dim3 grid((n + 7) / 8 * 32), block(64 * kQWaves);  // 32 workgroups = 8 quads, one per XCD
         if (a.T == 1) {  // one step: no exchange, no phases (gru_quad1_kernel)
+            const bool head = a.yw != nullptr && a.nb0 > 0;  // the previous stage's narrow head rides along
             if (a.nb0 == 0)
-                hipLaunchKernelGGL(gru_quad1_kernel<0>, grid, block, 0, s, g);
+                hipLaunchKernelGGL((gru_quad1_kernel<0, false>), grid, block, 0, s, g);
+            else if (a.nb0 == 1 && head)
+                hipLaunchKernelGGL((gru_quad1_kernel<1, true>), grid, block, 0, s, g);
             else if (a.nb0 == 1)
-                hipLaunchKernelGGL(gru_quad1_kernel<1>, grid, block, 0, s, g);
+                hipLaunchKernelGGL((gru_quad1_kernel<1, false>), grid, block, 0, s, g);
+            else if (head)
+                hipLaunchKernelGGL((gru_quad1_kernel<2, true>), grid, block, 0, s, g);
             else
-                hipLaunchKernelGGL(gru_quad1_kernel<2>, grid, block, 0, s, g);
+                hipLaunchKernelGGL((gru_quad1_kernel<2, false>), grid, block, 0, s, g);
             continue;
         }
         if (a.nb0 == 0)

@@ -132,6 +132,13 @@ struct GruQuadArgs {
     int quad0 = 0;      // first quad of this launch (set by launch_gru_quad: 64 quads per launch)
     unsigned long long *dbg = nullptr;  // developer build: [8 waves][4 T blocks][8] s_memtime stamps of workgroup `dbg_block`
     int dbg_block = 0;
+    // one-frame calls (T == 1), optional: the narrow head of the PREVIOUS stage computed inside this launch instead of in a launch
+    // of its own -- y_prev = sigmoid(h_B . W_head + b_head) of the quad's four m-tiles, straight into the staged x operand; a0 is
+    // not read then
+    const void *yh = nullptr;    // A-packed hidden sequence of the previous stage's layer B [mtiles][9]
+    const void *yw = nullptr;    // B-packed head weights [2 nb0][9]
+    const float *yb = nullptr;   // [2 nb0 * 16]
+    int yvalid = 0;              // head width (columns >= yvalid are zero)
 };
 // true when the shape is one the fused kernel takes (bf16, T >= 1, m-tiles in whole quads)
 bool gru_quad_supported(int precision, int mtiles, int nb0);
