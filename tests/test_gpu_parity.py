@@ -549,12 +549,12 @@ def test_baseline_config1_b256_fp32_at_its_stated_size(random_model, T, calls):
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
-@pytest.mark.parametrize('B,T', [(256, 1), (272, 1), (1072, 1), (1088, 1), (1104, 1), (1792, 1), (3072, 1), (3088, 1), (4096, 1), (4112, 1), (8192, 1), (3072, 2),
+@pytest.mark.parametrize('B,T', [(256, 1), (272, 1), (688, 1), (704, 1), (720, 1), (1792, 1), (3072, 1), (3088, 1), (4096, 1), (4112, 1), (8192, 1), (3072, 2),
                                  (3088, 2)])
 def test_dispatch_boundaries(random_model, precision, B, T):
     """The engine switches kernel families between one-frame calls below and above 192 m-tiles (bf16) / 256 m-tiles (fp32)
     (low-latency layer kernel vs input GEMM + recurrent kernel; 16 m-tiles was the edge in round 1), in bf16 already at
-    67 -> 68 m-tiles when the m-tiles make whole quads (one-step fused quad kernel; 69 m-tiles do not), and at 192 -> 193
+    43 -> 44 m-tiles when the m-tiles make whole quads (one-step fused quad kernel; 45 m-tiles do not), and at 192 -> 193
     m-tiles for several frames in fp32 (frame-by-frame layers vs chunked recurrence), kns_engine.cpp run_device().  Both
     sides of every edge, two calls each, every stream against the oracle."""
     base = synth_streams(128, 2 * T, seed=B)
