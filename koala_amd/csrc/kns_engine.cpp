@@ -720,8 +720,14 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     // with 16 workgroups -- 11.3 vs 5.2 M frames/s at 256 streams; the fp32 one streams them: 1.2 vs 2.8 M)
     const bool small_steps = T > 1 && mtb <= steps_mt && prec_ != kBf16 && !no_small_;
     auto gru_small = [&](const void *a0, int nb0, const void *a1, const void *wih, const float *bih, const void *whh,
-                         const float *bhh, int layer, void *hseq, int t = 0) {
+                         const float *bhh, int layer, void *hseq, int t = 0, const StageDev *head = nullptr) {
         GruSmallArgs g;
+        if (head) {  // the narrow head of the stage before, inside this launch (one-frame calls)
+            g.yh = d_hseq_b_;
+            g.yw = head->w_head;
+            g.yb = head->b_head;
+            g.yvalid = head->head_dim;
+        }
         const size_t frame = (size_t) t * mtb * 1024;  // bytes of one k-block column of A per frame
         g.a0 = a0 ? (const char *) a0 + frame * nb0 : nullptr;
         g.a1 = (const char *) a1 + frame * nbh_;
@@ -790,7 +796,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         const void *yprev = s ? d_y_[s - 1] : nullptr;
         const int nby = s ? nby_[s - 1] : 0;
         if (small) {
-            gru_small(yprev, nby, d_e_, d.w_ih_a, d.b_ih_a, d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_);
+            gru_small(yprev, nby, d_e_, d.w_ih_a, d.b_ih_a, d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_, 0, head_in_next ? &sd_[s - 1] : nullptr);
             gru_small(nullptr, 0, d_hseq_a_, d.w_ih_b, d.b_ih_b, d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_);
         } else if (small_steps) {
             for (int t = 0; t < T; ++t) gru_small(yprev, nby, d_e_, d.w_ih_a, d.b_ih_a, d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_, t);
@@ -810,8 +816,8 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
                 gru(d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_);
             }
         }
-        head_in_next = s < kStages - 1 && quad && T == 1 && fuse_head_ && nby_[s] >= 1 && nby_[s] <= quad_nb0_max_ &&
-                       d.head_tiles == 2 * nby_[s] && !debug_taps_;
+        head_in_next = s < kStages - 1 && T == 1 && fuse_head_ && nby_[s] >= 1 && d.head_tiles == pi_.npb * nby_[s] && !debug_taps_ &&
+                       (small || (quad && nby_[s] <= quad_nb0_max_));
         if (head_in_next)
             ;
         else if (s < kStages - 1)

@@ -132,7 +132,8 @@ __global__ __launch_bounds__(64 * W, W / 4) void gru_kernel(GruArgs g) {
 // ---- low-latency GRU layer: input GEMM + recurrent GEMM + gates of one frame, one wavefront per (unit tile, m-tile).
 // Arithmetic is, operation for operation, what the chunked path does (same MFMA, same k order, gi rounded to its storage
 // type before the gates, same gate formulas per precision), so a stream's samples do not depend on which path ran.
-template <class P, int NB0>  // NB0: k-blocks of the y part of the layer input (everything static: no branch around a load or an MFMA)
+// kHead: the y part is the previous stage's narrow head, computed here (every workgroup for its m-tile) instead of read
+template <class P, int NB0, bool kHead>  // NB0: k-blocks of the y part of the layer input (everything static: no branch around a load or an MFMA)
 __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
     // One workgroup per (unit tile, m-tile), one wave per gate: each wave streams only its gate's weights (a third of the
     // tile's), eight k-blocks of operands requested before the MFMAs that use them; the three accumulator pairs meet
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
     constexpr int NBH = P::NBH;
     __shared__ __attribute__((aligned(16))) char hbuf[NBH * 1024];
     __shared__ __attribute__((aligned(16))) char hspare[1024];
+    __shared__ __attribute__((aligned(16))) char ybuf[(NB0 > 0 ? NB0 : 1) * 1024];  // (kHead) the y part as A fragments
     __shared__ f32x4 xch[2][3][64];  // [input | recurrent][gate][lane]
     const int lane = threadIdx.x & 63;
     const int gt = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // this wave's gate: r, z, n
@@ -165,10 +167,26 @@ __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
     const frag_t *whh = (const frag_t *) g.whh + (size_t) (u * 3 + gt) * NBH * 64 + lane;
     const frag_t *a0 = (const frag_t *) g.a0 + (size_t) mt * NB0 * 64 + lane;
     const frag_t *a1 = (const frag_t *) g.a1 + (size_t) mt * NBH * 64 + lane;
+    // (kHead) NB0 k-blocks of NPB n-tiles = 1 .. 4 chains of NBH MFMAs, chain c on wave c mod 3; a wave whose slot is past the
+    // last chain repeats it (same values to the same words: no branch around the loads or the MFMAs)
+    constexpr int kChains = kHead ? NB0 * P::NPB : 1, kCw = (kChains + 2) / 3;
+    frag_t ya[kHead ? NBH : 1], yw[kCw][kHead ? NBH : 1];
+    float ybias[kCw];
+    if (kHead) {
+#pragma unroll
+        for (int p = 0; p < NBH; ++p) ya[p] = ((const frag_t *) g.yh)[((size_t) mt * NBH + p) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < kCw; ++q) {
+            const int c = gt + 3 * q < kChains ? gt + 3 * q : kChains - 1;
+#pragma unroll
+            for (int p = 0; p < NBH; ++p) yw[q][p] = ((const frag_t *) g.yw)[((size_t) c * NBH + p) * 64 + lane];
+            ybias[q] = g.yb[c * 16 + colq];
+        }
+    }
     frag_t xa[nb], wi[nb], wh[NBH];
 #pragma unroll
     for (int p = 0; p < nb; ++p) {
-        xa[p] = p < NB0 ? a0[(size_t) p * 64] : a1[(size_t) (p - NB0) * 64];
+        if (!(kHead && p < NB0)) xa[p] = p < NB0 ? a0[(size_t) p * 64] : a1[(size_t) (p - NB0) * 64];
         wi[p] = wih[(size_t) p * 64];
     }
 #pragma unroll
@@ -191,13 +209,35 @@ __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
     }
     static_assert(3 * kHT * 16 >= NBH * P::KB, "the three waves' tile slots cover the operand image");
 
+    if (kHead) {  // y_prev = sigmoid(h_B . W_head + b_head), columns >= yvalid zero, rounded to the operand type (what the head GEMM stores)
+#pragma unroll
+        for (int q = 0; q < kCw; ++q) {
+            const int c = gt + 3 * q < kChains ? gt + 3 * q : kChains - 1;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int p = 0; p < NBH; ++p) acc = P::mma(ya[p], yw[q][p], acc);
+            elem_t *sc = (elem_t *) ybuf + (c / P::NPB) * 64 * P::EPL;
+            const bool pad = c * 16 + colq >= g.yvalid;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float x = pad ? 0.0f : head_sigmoid<P>(acc[i] + ybias[q]);
+                sc[P::off(rowq + i, (c % P::NPB) * 16 + colq)] = P::cvt(x);
+            }
+        }
+    }
     f32x4 acci = f32x4{0.f, 0.f, 0.f, 0.f}, acch = f32x4{0.f, 0.f, 0.f, 0.f};
     if (P::kPrec == kBf16) acch = f32x4{bh, bh, bh, bh};  // bf16 configuration: this gate's recurrent chain starts from its b_hh
+    if (!kHead) {
 #pragma unroll
-    for (int p = 0; p < nb; ++p) acci = P::mma(xa[p], wi[p], acci);
-    __syncthreads();  // hbuf complete
+        for (int p = 0; p < nb; ++p) acci = P::mma(xa[p], wi[p], acci);
+    }
+    __syncthreads();  // hbuf (and ybuf) complete
 #pragma unroll
     for (int p = 0; p < NBH; ++p) acch = P::mma(((const frag_t *) hbuf)[p * 64 + lane], wh[p], acch);
+    if (kHead) {  // the input-side chain after the barrier: its first NB0 blocks are the head's output
+#pragma unroll
+        for (int p = 0; p < nb; ++p) acci = P::mma(p < NB0 ? ((const frag_t *) ybuf)[p * 64 + lane] : xa[p], wi[p], acci);
+    }
     {
         f32x4 v = acci;
 #pragma unroll
@@ -236,18 +276,19 @@ __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
 void launch_gru_small(const GruSmallArgs &a, hipStream_t s) {
     dim3 grid(kUnitTiles, a.mtiles);
     auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(192), 0, s, a); };
+    const bool head = a.yw != nullptr && a.nb0 > 0;  // the previous stage's narrow head rides along
     if (a.precision == kBf16) {
         switch (a.nb0) {
-            case 0: go(gru_small_kernel<PBF16, 0>); break;
-            case 1: go(gru_small_kernel<PBF16, 1>); break;
-            default: go(gru_small_kernel<PBF16, 2>); break;
+            case 0: go(gru_small_kernel<PBF16, 0, false>); break;
+            case 1: head ? go(gru_small_kernel<PBF16, 1, true>) : go(gru_small_kernel<PBF16, 1, false>); break;
+            default: head ? go(gru_small_kernel<PBF16, 2, true>) : go(gru_small_kernel<PBF16, 2, false>); break;
         }
     } else {
         switch (a.nb0) {
-            case 0: go(gru_small_kernel<PF32, 0>); break;
-            case 1: go(gru_small_kernel<PF32, 1>); break;
-            case 2: go(gru_small_kernel<PF32, 2>); break;
-            default: go(gru_small_kernel<PF32, 3>); break;
+            case 0: go(gru_small_kernel<PF32, 0, false>); break;
+            case 1: head ? go(gru_small_kernel<PF32, 1, true>) : go(gru_small_kernel<PF32, 1, false>); break;
+            case 2: head ? go(gru_small_kernel<PF32, 2, true>) : go(gru_small_kernel<PF32, 2, false>); break;
+            default: head ? go(gru_small_kernel<PF32, 3, true>) : go(gru_small_kernel<PF32, 3, false>); break;
         }
     }
 }

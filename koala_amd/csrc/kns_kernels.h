@@ -107,6 +107,12 @@ struct GruSmallArgs {
     float *hstate_out;
     void *hseq;         // A-packed [mtiles][nbh], out (this frame's h as the next kernel's A operand)
     int nb0, mtiles, precision;
+    // optional: the narrow head of the PREVIOUS stage computed inside this launch (y_prev = sigmoid(h_B . W_head + b_head) of the
+    // workgroup's m-tile, every workgroup for itself); a0 is not read then
+    const void *yh = nullptr;    // A-packed hidden sequence of the previous stage's layer B [mtiles][nbh]
+    const void *yw = nullptr;    // B-packed head weights [n-tiles][nbh]
+    const float *yb = nullptr;
+    int yvalid = 0;              // head width (columns >= yvalid are zero)
 };
 void launch_gru_small(const GruSmallArgs &a, hipStream_t s);
 

@@ -326,7 +326,8 @@ import torch  # noqa: F401  (first: see conftest)
 import koala_amd
 from koala_amd.workload import synth_streams
 h = hashlib.sha256()
-for precision, B, T in (('bf16', 4096, 4), ('bf16', 4096, 1), ('bf16', 272, 3), ('bf16', 320, 5), ('fp32', 512, 2)):
+for precision, B, T in (('bf16', 4096, 4), ('bf16', 4096, 1), ('bf16', 272, 3), ('bf16', 320, 5), ('fp32', 512, 2), ('bf16', 272, 1),
+                        ('fp32', 48, 1), ('bf16', 704, 1)):
     x = np.tile(synth_streams(16, 2 * T, seed=9), ((B + 15) // 16, 1))[:B]
     kb = koala_amd.create_batch('key', B, T, precision, model_path=%(model)r, library_path=%(lib)r)
     for c in range(2):
