@@ -705,10 +705,10 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     // 192 m-tiles in bf16 (3 072 streams: 218 vs 264 us per frame step; 512 streams: 113 vs 212; at 4 096 it loses, 256 vs
     // 222) and at every size measured in fp32 (4 096 streams: 628 vs 815 us).  Same arithmetic, bit for bit.
     const int small_env = dev_small_mt_;
-    // (bf16, m-tiles in whole quads: from 44 m-tiles on the one-step quad kernel is faster -- it takes ~94 us per frame step from
-    // 512 to 1 088 streams, 96 at 2 048, 106 at 4 096 (222 with the chunked kernels); the low-latency kernel below 90 us at 512
-    // streams, 92 at 640, 98 at 768)
-    const int small_mt = small_env > 0 ? small_env : (prec_ == kBf16 ? (use_quad_ ? 43 : 192) : 256);
+    // (bf16, m-tiles in whole quads: from 60 m-tiles on the one-step quad kernel is faster -- it takes ~94 us per frame step from
+    // 512 to 1 536 streams, 96 at 2 048, 106 at 4 096 (222 with the chunked kernels); the low-latency kernel below 79 us at 512
+    // streams, 81 at 704, 99 at 1 024, 120 at 1 536)
+    const int small_mt = small_env > 0 ? small_env : (prec_ == kBf16 ? (use_quad_ ? 59 : 192) : 256);
     const bool small = T == 1 && mtb <= small_mt && !no_small_;
     // Fewer than 256 m-tiles: the chunked recurrent kernels would occupy mtb workgroups, so the layers run frame
     // by frame through the low-latency kernel instead (17 x mtb workgroups of three waves per frame, input GEMM included):

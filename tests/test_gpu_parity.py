@@ -327,7 +327,7 @@ import koala_amd
 from koala_amd.workload import synth_streams
 h = hashlib.sha256()
 for precision, B, T in (('bf16', 4096, 4), ('bf16', 4096, 1), ('bf16', 272, 3), ('bf16', 320, 5), ('fp32', 512, 2), ('bf16', 272, 1),
-                        ('fp32', 48, 1), ('bf16', 704, 1)):
+                        ('fp32', 48, 1), ('bf16', 960, 1)):
     x = np.tile(synth_streams(16, 2 * T, seed=9), ((B + 15) // 16, 1))[:B]
     kb = koala_amd.create_batch('key', B, T, precision, model_path=%(model)r, library_path=%(lib)r)
     for c in range(2):
@@ -550,12 +550,12 @@ def test_baseline_config1_b256_fp32_at_its_stated_size(random_model, T, calls):
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
-@pytest.mark.parametrize('B,T', [(256, 1), (272, 1), (688, 1), (704, 1), (720, 1), (1792, 1), (3072, 1), (3088, 1), (4096, 1), (4112, 1), (8192, 1), (3072, 2),
+@pytest.mark.parametrize('B,T', [(256, 1), (272, 1), (944, 1), (960, 1), (976, 1), (1792, 1), (3072, 1), (3088, 1), (4096, 1), (4112, 1), (8192, 1), (3072, 2),
                                  (3088, 2)])
 def test_dispatch_boundaries(random_model, precision, B, T):
     """The engine switches kernel families between one-frame calls below and above 192 m-tiles (bf16) / 256 m-tiles (fp32)
     (low-latency layer kernel vs input GEMM + recurrent kernel; 16 m-tiles was the edge in round 1), in bf16 already at
-    43 -> 44 m-tiles when the m-tiles make whole quads (one-step fused quad kernel; 45 m-tiles do not), and at 192 -> 193
+    59 -> 60 m-tiles when the m-tiles make whole quads (one-step fused quad kernel; 61 m-tiles do not), and at 192 -> 193
     m-tiles for several frames in fp32 (frame-by-frame layers vs chunked recurrence), kns_engine.cpp run_device().  Both
     sides of every edge, two calls each, every stream against the oracle."""
     base = synth_streams(128, 2 * T, seed=B)
