@@ -742,9 +742,16 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad1_kernel(GruQuadArgs 
         acc[m][2] = f32x4{b2, b2, b2, b2};
     }
     const frag_t *hs = (const frag_t *) (smem + kQ1OffHs) + lane;
+    // the previous state of the tiles this wave finishes after barrier B: requested once the last weights are (k-block 9 - kQ1Ahead),
+    // so that it is there when the gates start and waits in registers for a few k-blocks only
+    f32x4 hp[4];
 #pragma unroll
     for (int blk = 0; blk < 9; ++blk) {
         if (blk + kQ1Ahead < 9) request(blk + kQ1Ahead);
+        if (blk == 9 - kQ1Ahead) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) hp[m] = ((const f32x4 *) g.hstate_in)[((size_t) (mt0 + m) * kUnitTiles + u) * 64 + lane];
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const frag_t a = hs[(m * 9 + blk) * 64];
@@ -755,10 +762,6 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad1_kernel(GruQuadArgs 
         __builtin_amdgcn_sched_barrier(0);
     }
     if (j < 3) *(f32x4 *) (smem + kQ1OffGh16 + j * 1024 + lane * 16) = a16;
-    // the previous state of the tiles this wave finishes: requested here, behind the weights
-    f32x4 hp[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) hp[m] = ((const f32x4 *) g.hstate_in)[((size_t) (mt0 + m) * kUnitTiles + u) * 64 + lane];
     stamp(4);
     __syncthreads();  // barrier B
     stamp(5);

@@ -550,7 +550,7 @@ def test_baseline_config1_b256_fp32_at_its_stated_size(random_model, T, calls):
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
-@pytest.mark.parametrize('B,T', [(256, 1), (272, 1), (944, 1), (960, 1), (976, 1), (1792, 1), (3072, 1), (3088, 1), (4096, 1), (4112, 1), (8192, 1), (3072, 2),
+@pytest.mark.parametrize('B,T', [(256, 1), (272, 1), (944, 1), (960, 1), (976, 1), (1792, 1), (3072, 1), (3088, 1), (4090, 1), (4096, 1), (4112, 1), (8192, 1), (3072, 2),
                                  (3088, 2)])
 def test_dispatch_boundaries(random_model, precision, B, T):
     """The engine switches kernel families between one-frame calls below and above 192 m-tiles (bf16) / 256 m-tiles (fp32)
