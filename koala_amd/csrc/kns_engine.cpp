@@ -303,7 +303,8 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     // turns it off everywhere).
     quad_all_ = dev_env("KOALA_AMD_QUAD") != nullptr;
     use_quad_ = dev_env("KOALA_AMD_NO_QUAD") == nullptr;
-    fuse_head_ = dev_env("KOALA_AMD_NO_HEAD_FUSE") == nullptr;  // A/B arm: narrow heads as launches of their own in one-frame calls
+    fuse_head_ = dev_env("KOALA_AMD_NO_HEAD_FUSE") == nullptr;
+    fuse_front_ = dev_env("KOALA_AMD_NO_STFT_FUSE") == nullptr;  // A/B arm: front-end / mask head as launches of their own in one-frame calls  // A/B arm: narrow heads as launches of their own in one-frame calls
     quad_nb0_max_ = dev_int("KOALA_AMD_QUAD_NB0MAX", 2);
     qdbg_block_ = dev_int("KOALA_AMD_QUAD_DBG", -1);
     // host-pointer calls are cut into sub-chunks of host_chunk_ frames (two staging slots = the Tmax-sized buffers)
@@ -653,6 +654,16 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         while (seg > 4 && (Bpad_ / 16) * ((T + seg - 1) / seg) < 1024) seg = (seg + 1) / 2;
         an.seg = seg_env > 0 ? (seg_env < T ? seg_env : T) : seg;
     }
+    // One-frame calls (bf16, one-frame front-end): the front-end GEMM rides in the analysis launch (kns_stft.hip, kFront) -- the
+    // feature tile never leaves the CU and a frame step is one launch shorter.
+    const bool front_in_analysis = T == 1 && prec_ == kBf16 && taps_ == 1 && fuse_front_ && !debug_taps_ && an.write_spec;
+    if (front_in_analysis) {
+        an.front_w = w_in_;
+        an.front_b = b_in_;
+        an.front_out = d_e_;
+        an.front_valid = kHidden;
+        an.feat = nullptr;
+    }
     const int16_t *hist_before = d_hist_[hist_cur_];
     const int only = dev_only_class_;  // -1 in the product library
     tick(kClsAnalysis);
@@ -784,7 +795,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     };
 
     // front-end: e = features . W_in + b_in
-    gemm(kClsGemmHead, nullptr, 0, d_feat_, nbf_, w_in_, b_in_, d_e_, nbh_ * pi_.npb, kHidden, kOutAPlain, taps_);
+    if (!front_in_analysis) gemm(kClsGemmHead, nullptr, 0, d_feat_, nbf_, w_in_, b_in_, d_e_, nbh_ * pi_.npb, kHidden, kOutAPlain, taps_);
     if (taps_ > 1)  // the last taps - 1 frames of [context | call] are the next call's context
         (void) hipMemcpyAsync(d_fhist_, (char *) d_feat_ + (size_t) T * feat_frame_bytes_, (size_t) (taps_ - 1) * feat_frame_bytes_,
                               hipMemcpyDeviceToDevice, stream_);

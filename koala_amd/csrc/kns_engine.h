@@ -114,7 +114,7 @@ private:
     unsigned quad_serial_ = 0;
     bool use_quad_ = true, quad_all_ = false, quad_used_ = false;
     int quad_nb0_max_ = 2;
-    bool fuse_head_ = true;
+    bool fuse_head_ = true, fuse_front_ = true;
     bool check_quad_error(std::string *err);
     unsigned long long *d_qdbg_ = nullptr;  // developer build, KOALA_AMD_QUAD_DBG=<block>: stamps of the LAST fused launch
     int qdbg_block_ = -1;

@@ -363,7 +363,7 @@ def test_alternative_kernels_give_identical_pcm(random_model, random5_model):
                                'lib': DEV_LIB}
     for switch in ('', 'KOALA_AMD_GRU_STREAM', 'KOALA_AMD_GEMM_GENERIC',
                    'KOALA_AMD_GEMM_NO_WSR', 'KOALA_AMD_NO_SMALL', 'KOALA_AMD_NO_GRAPH', 'KOALA_AMD_STORE_SPECTRUM',
-                   'KOALA_AMD_DEBUG_TAPS', 'KOALA_AMD_QUAD', 'KOALA_AMD_NO_QUAD', 'KOALA_AMD_NO_HEAD_FUSE'):  # (GRU layers as one launch fused over CU quads,
+                   'KOALA_AMD_DEBUG_TAPS', 'KOALA_AMD_QUAD', 'KOALA_AMD_NO_QUAD', 'KOALA_AMD_NO_HEAD_FUSE', 'KOALA_AMD_NO_STFT_FUSE'):  # (GRU layers as one launch fused over CU quads,
         # kns_gruq.hip: everywhere / nowhere; the product takes it for one-frame calls of large batches)
         env = dict(os.environ)
         if switch:
