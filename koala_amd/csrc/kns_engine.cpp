@@ -801,6 +801,9 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
                               hipMemcpyDeviceToDevice, stream_);
     // One-frame calls through the quad kernel: the narrow head of stage s (271 -> 1, 5, 40) is computed inside stage s + 1's first
     // layer launch instead of in a launch of its own (kns_gruq.hip, kHead): 15 launches per frame step become 12.
+    // ... and the mask head in the synthesis launch (bf16, stored spectrum -- what a one-frame call uses; kns_stft.hip, kMaskIn)
+    const bool mask_in_synthesis = T == 1 && prec_ == kBf16 && fuse_front_ && !debug_taps_ && !recompute &&
+                                   sd_[kStages - 1].head_tiles == kMaskTiles;
     bool head_in_next = false;  // stage s - 1's head has been left to this stage's first layer
     for (int s = 0; s < kStages; ++s) {
         const StageDev &d = sd_[s];
@@ -834,7 +837,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         else if (s < kStages - 1)
             gemm(kClsGemmHead, nullptr, 0, d_hseq_b_, nbh_, d.w_head, d.b_head, d_y_[s], d.head_tiles, d.head_dim,
                  kOutASigmoid);
-        else
+        else if (!mask_in_synthesis)
             gemm(kClsGemmHead, nullptr, 0, d_hseq_b_, nbh_, d.w_head, d.b_head, d_mask_, d.head_tiles, kBins, kOutMask);
     }
 
@@ -858,6 +861,11 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     sy.hist_in = hist_before;
     sy.recompute = recompute;
     sy.mask_fp16 = prec_ == kBf16;
+    if (mask_in_synthesis) {
+        sy.mask_h = d_hseq_b_;
+        sy.mask_w = sd_[kStages - 1].w_head;
+        sy.mask_b = sd_[kStages - 1].b_head;
+    }
     sy.B = B_;
     sy.Bpad = Bpad_;
     sy.T = T;

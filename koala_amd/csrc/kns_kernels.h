@@ -58,6 +58,11 @@ struct SynthesisArgs {
     const int16_t *hist_in; // ... and the history the analysis kernel started from, [Bpad][256]
     int recompute;          // rebuild each frame's spectrum from its PCM instead of reading `spec`
     int mask_fp16 = 0;
+    // optional (one-frame calls, bf16, stored spectrum): the mask head sigmoid(h . W_mask + b_mask) inside this launch -- four
+    // further waves compute the workgroup's mask tile into LDS while the STFT waves fetch their operands; `mask` is not read then
+    const void *mask_h = nullptr;    // A-packed hidden sequence of the last stage's layer B [mtiles][9]
+    const void *mask_w = nullptr;    // B-packed [17][9]
+    const float *mask_b = nullptr;   // [17 * 16]
 };
 void launch_synthesis(const SynthesisArgs &a, hipStream_t s);
 

@@ -241,11 +241,45 @@ void launch_analysis(const AnalysisArgs &a, hipStream_t s) {
 // updates the history in place and the previous frame is gone by the time this kernel runs.
 // (three waves per SIMD: the kernel is bound by VALU issue, and two waves on a SIMD reach an instruction every ~2.8 cycles,
 // three come close to the pipe's 2; the register budget of 168 is what decides which loads are prefetched below)
-template <bool kRecompute, bool kMaskH>  // kMaskH: the mask travels as fp16 C fragments (bf16 configuration), else fp32
-__global__ __launch_bounds__(256, 3) void synthesis_kernel(SynthesisArgs g) {
+// kMaskIn (one-frame calls, bf16): waves 4..7 are the mask head -- sigmoid(h . W_mask + b_mask) of the workgroup's m-tile as fp16 C
+// fragments in LDS (what gemm_kernel<kOutMask> stores), complete at the workgroup's one barrier; the STFT waves read it from there.
+template <bool kRecompute, bool kMaskH, bool kMaskIn>  // kMaskH: the mask travels as fp16 C fragments (bf16 configuration), else fp32
+__global__ __launch_bounds__(kMaskIn ? 512 : 256, kMaskIn ? 1 : 3) void synthesis_kernel(SynthesisArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(!kMaskIn || (kMaskH && !kRecompute), "mask head inside: bf16, stored spectrum");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (kMaskIn && wave >= 4) {
+        typedef PBF16 P;
+        typedef P::frag_t frag_t;
+        constexpr int NB = P::NBH, kPer = (kMaskTiles + 3) / 4;
+        const int gw = wave - 4, colq = lane & 15;
+        frag_t a[NB], w[kPer][NB];
+        float bias[kPer];
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) a[kb] = ((const frag_t *) g.mask_h)[((size_t) blockIdx.x * NB + kb) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {  // n-tiles gw, gw + 4, ...; a slot past the last tile repeats it (same words, same values)
+            const int nt = gw + 4 * q < kMaskTiles ? gw + 4 * q : kMaskTiles - 1;
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) w[q][kb] = ((const frag_t *) g.mask_w)[((size_t) nt * NB + kb) * 64 + lane];
+            bias[q] = g.mask_b[nt * 16 + colq];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // every request before the first use (the scheduler would sink the loads to save registers)
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const int nt = gw + 4 * q < kMaskTiles ? gw + 4 * q : kMaskTiles - 1;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) acc = P::mma(a[kb], w[q][kb], acc);
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = head_sigmoid<P>(acc[i] + bias[q]);
+            ((f16x4 *) (smem + kOffStftEnd))[nt * 64 + lane] = __builtin_convertvector(v, f16x4);
+        }
+        __syncthreads();
+        return;
+    }
     const int c = fft_column(lane), q = lane >> 4, row = wave * 4 + q;
     const int mt = blockIdx.x, mtiles = g.Bpad >> 4;
     const int t0 = blockIdx.y * g.seg, t1 = min(g.T, t0 + g.seg);
@@ -270,18 +304,18 @@ __global__ __launch_bounds__(256, 3) void synthesis_kernel(SynthesisArgs g) {
             tl[j] = cpx{v.x, v.y};
         }
     }
-    stft_load_tables<true>(smem, g.twiddle, g.window, tid);
-    __syncthreads();
-    char *xw;
-    const char *xr, *twl_c;
-    fft_lane_bases(smem + kOffXbuf + wave * kFftWaveBytes, smem + kOffTwl, lane, &xw, &xr, &twl_c);
-    const char *tw_c = smem + kOffTw + c * 8, *win_c = smem + kOffWin + c * 8, *wins_c = smem + kOffWinS + c * 8;
-
     // mask element (row, k): C-packed tile k / 16, lane (row >> 2) * 16 + (k & 15), value row & 3 -- for a fixed k2 the
     // wave reads one contiguous 1 KiB tile
     const unsigned mlane = ((unsigned) (wave * 16 + c) * 4u + (unsigned) q) * 4u;
     float mk[17], mkn[17];
     auto mask_fetch = [&](float (&m)[17], int t) {
+        if (kMaskIn) {  // this workgroup's tile, computed by waves 4..7 into LDS
+            const _Float16 *ml = (const _Float16 *) (smem + kOffStftEnd);
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) m[k2] = (float) ml[k2 * 256 + (mlane >> 2)];
+            m[16] = (float) ml[16 * 256 + (wave * 16) * 4 + q];
+            return;
+        }
         if (kMaskH) {  // fp16 tiles of 512 B; the conversion to fp32 is exact
             const __amdgpu_buffer_rsrc_t mr =
                 make_rsrc((const char *) g.mask + ((size_t) t * mtiles + mt) * kMaskTiles * 512, kMaskTiles * 512);
@@ -308,10 +342,19 @@ __global__ __launch_bounds__(256, 3) void synthesis_kernel(SynthesisArgs g) {
             dst[k2 + 1] = cpx{v[2], v[3]};
         }
     };
+    // stored spectrum: the first frame's operands are requested before the tables are waited for (one memory round trip in front
+    // of the first FFT, not two)
     if (!kRecompute) {
-        mask_fetch(mk, tb);
+        if (!kMaskIn) mask_fetch(mk, tb);
         spec_fetch(xs, tb);
     }
+    stft_load_tables<true>(smem, g.twiddle, g.window, tid);
+    __syncthreads();
+    char *xw;
+    const char *xr, *twl_c;
+    fft_lane_bases(smem + kOffXbuf + wave * kFftWaveBytes, smem + kOffTwl, lane, &xw, &xr, &twl_c);
+    const char *tw_c = smem + kOffTw + c * 8, *win_c = smem + kOffWin + c * 8, *wins_c = smem + kOffWinS + c * 8;
+    if (kMaskIn) mask_fetch(mk, tb);  // (complete since the barrier)
 
     for (int t = tb; t < t1; ++t) {
         const bool emit = t >= t0;
@@ -412,14 +455,16 @@ __global__ __launch_bounds__(256, 3) void synthesis_kernel(SynthesisArgs g) {
 void launch_synthesis(const SynthesisArgs &a, hipStream_t s) {
     const size_t lds = kOffStftEnd;
     const dim3 grid(a.Bpad / 16, (a.T + a.seg - 1) / a.seg);
-    if (a.recompute && a.mask_fp16)
-        hipLaunchKernelGGL((synthesis_kernel<true, true>), grid, dim3(256), lds, s, a);
+    if (a.mask_w && !a.recompute && a.mask_fp16 && a.T == 1)
+        hipLaunchKernelGGL((synthesis_kernel<false, true, true>), grid, dim3(512), lds + kMaskTiles * 512, s, a);
+    else if (a.recompute && a.mask_fp16)
+        hipLaunchKernelGGL((synthesis_kernel<true, true, false>), grid, dim3(256), lds, s, a);
     else if (a.recompute)
-        hipLaunchKernelGGL((synthesis_kernel<true, false>), grid, dim3(256), lds, s, a);
+        hipLaunchKernelGGL((synthesis_kernel<true, false, false>), grid, dim3(256), lds, s, a);
     else if (a.mask_fp16)
-        hipLaunchKernelGGL((synthesis_kernel<false, true>), grid, dim3(256), lds, s, a);
+        hipLaunchKernelGGL((synthesis_kernel<false, true, false>), grid, dim3(256), lds, s, a);
     else
-        hipLaunchKernelGGL((synthesis_kernel<false, false>), grid, dim3(256), lds, s, a);
+        hipLaunchKernelGGL((synthesis_kernel<false, false, false>), grid, dim3(256), lds, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------ reset
