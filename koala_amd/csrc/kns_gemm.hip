@@ -674,7 +674,7 @@ static void launch_gemm_mt(const GemmArgs &a, hipStream_t s) {
     const size_t lds = (size_t) MT * nb * 1024 + 4 * MT * 1024;
     dim3 grid(gx, gy);
     auto go = [&](auto kernel) {
-        if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);  // (the size varies per call)
         hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, a);
     };
     switch (a.out_kind) {
@@ -746,11 +746,7 @@ void launch_gemm(const GemmArgs &a, hipStream_t s) {
             seglen = (seglen + kF5P - 1) / kF5P * kF5P;
             nseg = (T + seglen - 1) / seglen;
             const int jobs = mtb * nseg;
-            static bool attr = false;
-            if (!attr) {
-                (void) hipFuncSetAttribute((const void *) gemm_front5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kF5LdsBytes);
-                attr = true;
-            }
+            allow_dynamic_lds(gemm_front5_kernel, kF5LdsBytes);
             hipLaunchKernelGGL(gemm_front5_kernel, dim3((jobs + 7) / 8 * 24), dim3(64 * kF5Waves), kF5LdsBytes, s, a, mtb, T, seglen);
             return;
         }

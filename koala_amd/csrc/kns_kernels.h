@@ -9,6 +9,20 @@
 
 namespace kns {
 
+// A kernel that asks for more dynamic LDS than the default limit needs the attribute once PER DEVICE (a process may hold
+// engines on several GPUs): remembered per kernel instantiation and device.
+template <class Kernel>
+inline void allow_dynamic_lds(Kernel kernel, size_t bytes) {
+    static unsigned long long done = 0;  // bit d: set on device d (launches of one engine come from one thread at a time)
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done & bit) return;
+    (void) hipFuncSetAttribute((const void *) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
+    done |= bit;
+}
+
+
 // Developer switches (kernel A/B selection, tuning knobs, probing modes) exist only in the -DKNS_DEV build
 // (lib/libpv_koala_dev.so, used by tests/ and tools/); the product library reads none of them.
 #ifdef KNS_DEV

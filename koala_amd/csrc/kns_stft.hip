@@ -212,12 +212,7 @@ void launch_analysis(const AnalysisArgs &a, hipStream_t s) {
     if (a.precision == kBf16) {
         if (a.front_w && a.T == 1 && a.write_spec) {  // the front-end GEMM inside (one frame: one loop iteration, three barriers)
             const size_t ldsf = lds + PBF16::NBH * 1024;
-            static bool attr = false;
-            if (!attr) {
-                (void) hipFuncSetAttribute((const void *) analysis_kernel<PBF16, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int) ldsf);
-                attr = true;
-            }
+            allow_dynamic_lds(analysis_kernel<PBF16, true, true>, ldsf);
             hipLaunchKernelGGL((analysis_kernel<PBF16, true, true>), grid, dim3(512), ldsf, s, a);
         } else if (a.write_spec)
             hipLaunchKernelGGL((analysis_kernel<PBF16, true, false>), grid, dim3(256), lds, s, a);
