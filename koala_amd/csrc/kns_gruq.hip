@@ -658,8 +658,8 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad1_kernel(GruQuadArgs 
         f32x4 hp16 = f32x4{0.f, 0.f, 0.f, 0.f};
         if (j == 3) hp16 = ((const f32x4 *) g.hstate_in)[((size_t) (mt0 + c) * kUnitTiles + 16) * 64 + lane];
         stamp(1);
-        head();
         images();
+        head();
         stamp(2);
         __syncthreads();  // barrier A
         stamp(3);
@@ -729,8 +729,8 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad1_kernel(GruQuadArgs 
     const float b0 = g.bhh[(u * 3 + 0) * 16 + colq], b1 = g.bhh[(u * 3 + 1) * 16 + colq], b2 = g.bhh[(u * 3 + 2) * 16 + colq];
     const float b16 = g.bhh[(16 * 3 + (j < 3 ? j : 0)) * 16 + colq];
     stamp(1);
-    head();
     images();
+    head();
     stamp(2);
     __syncthreads();  // barrier A
     stamp(3);
