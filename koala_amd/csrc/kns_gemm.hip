@@ -662,6 +662,55 @@ __global__ __launch_bounds__(64 * kF5Waves) void gemm_front5_kernel(GemmArgs g, 
     }
 }
 
+// ---- the five-frame front-end of a ONE-frame call (or of a few frames: one workgroup triple per m-tile of stream-frames): the same
+// split -- six n-tiles per workgroup, one n-tile with all 45 k-blocks per wave -- but nothing to walk: the wave's 45 weight
+// fragments and the m-tile's five feature tiles (global -> LDS directly) are requested at once, one memory round trip, 45 MFMAs.
+// (gemm_kernel needs ~25 us for this shape: it streams the 810 KiB through a four-deep queue per unit.)
+constexpr int kF5tLdsBytes = kF5Taps * kF5TileBytes + 3 * 1024;
+
+__global__ __launch_bounds__(64 * kF5Waves) void gemm_front5_t1_kernel(GemmArgs g) {
+    typedef PBF16 P;
+    typedef P::frag_t frag_t;
+    constexpr int NB = P::NBH, NK = kF5Taps * NB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    const int mt = (b / 24) * 8 + (b & 7), c = (b >> 3) % 3;  // the triple of an m-tile on one XCD: blocks b, b + 8, b + 16
+    if (mt >= g.mtiles) return;
+    const int colq = lane & 15, nt = 6 * c + wave;
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    for (int i = wave; i < NK; i += kF5Waves) {
+        const int tap = i / NB, kb = i - tap * NB;
+        __builtin_amdgcn_global_load_lds(
+            (gptr_t) ((const frag_t *) ((const char *) g.a1 + tap * g.tap_stride) + ((size_t) mt * NB + kb) * 64 + lane),
+            (lptr_t) (smem + i * 1024), 16, 0, 0);
+    }
+    frag_t w[NK];
+    {
+        const frag_t *wp = (const frag_t *) g.w + (size_t) nt * NK * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) w[k] = wp[k * 64];
+    }
+    const float bias = g.bias[nt * 16 + colq];
+    const bool pad = nt * 16 + colq >= g.n_valid;
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NK; ++k) acc = P::mma(((const frag_t *) smem)[k * 64 + lane], w[k], acc);
+    char *outb = smem + kF5Taps * kF5TileBytes;
+    {
+        uint16_t *sc = (uint16_t *) (outb + (wave >> 1) * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sc[P::off((lane >> 4) * 4 + i, (wave & 1) * 16 + colq)] = P::cvt(pad ? 0.0f : acc[i] + bias);
+    }
+    __syncthreads();
+    if (wave < 3)
+        ((frag_t *) g.out)[(((size_t) mt * (g.ntiles / 2)) + 3 * c + wave) * 64 + lane] = ((const frag_t *) (outb + wave * 1024))[lane];
+}
+
 template <class P, int MT>
 static void launch_gemm_mt(const GemmArgs &a, hipStream_t s) {
     const int nb = a.nb0 + a.taps * a.nb1;
@@ -748,6 +797,11 @@ void launch_gemm(const GemmArgs &a, hipStream_t s) {
             const int jobs = mtb * nseg;
             allow_dynamic_lds(gemm_front5_kernel, kF5LdsBytes);
             hipLaunchKernelGGL(gemm_front5_kernel, dim3((jobs + 7) / 8 * 24), dim3(64 * kF5Waves), kF5LdsBytes, s, a, mtb, T, seglen);
+            return;
+        }
+        if (a.mtiles <= 1024) {  // one frame (or a few) per call: no time to walk
+            allow_dynamic_lds(gemm_front5_t1_kernel, kF5tLdsBytes);
+            hipLaunchKernelGGL(gemm_front5_t1_kernel, dim3((a.mtiles + 7) / 8 * 24), dim3(64 * kF5Waves), kF5tLdsBytes, s, a);
             return;
         }
     }

@@ -334,7 +334,7 @@ for precision, B, T in (('bf16', 4096, 4), ('bf16', 4096, 1), ('bf16', 272, 3), 
         h.update(kb.process(np.ascontiguousarray(x[:, c * T * 256:(c + 1) * T * 256])).tobytes())
     kb.delete()
 # the five-frame front-end (KNS-v1.1): weight-stationary over workgroup triples vs the generic GEMM, ragged segment ends
-for B, T in ((272, 9), (48, 37), (1024, 8)):
+for B, T in ((272, 9), (48, 37), (1024, 8), (272, 2), (64, 1), (4096, 1)):  # (the last three: the one-frame form of the kernel)
     x = np.tile(synth_streams(16, 2 * T, seed=11), ((B + 15) // 16, 1))[:B]
     kb = koala_amd.create_batch('key', B, T, 'bf16', model_path=%(model5)r, library_path=%(lib)r)
     for c in range(2):
