@@ -411,7 +411,9 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     feat_frame_bytes_ = mtb * nbf_ * 1024;
     d_feat_ = dalloc((M + (size_t) (taps_ - 1) * mtb) * nbf_ * 1024, true);  // [context frames | the call's frames]
     if (taps_ > 1) {
-        d_fhist_ = dalloc((size_t) (taps_ - 1) * feat_frame_bytes_, true);
+        // taps_ slots: slots 1 .. taps_ - 1 hold the features of the last taps_ - 1 frames; slot 0 is where a one-frame call's roll
+        // puts the oldest tap (kns_stft.hip, AnalysisArgs::feat_hist)
+        d_fhist_ = dalloc((size_t) taps_ * feat_frame_bytes_, true);
         // one m-tile whose 16 rows are the feature of a silent frame, in the operand type and layout of `feat`
         std::vector<uint8_t> tile((size_t) nbf_ * 1024, 0);
         const float lg = host_kns_log(1e-10f);
@@ -590,7 +592,7 @@ bool Engine::reset(const uint8_t *host_mask, std::string *err) {
     r.Bpad = Bpad_;
     r.fhist = d_fhist_;
     r.silent = d_silent_;
-    r.fhist_frames = taps_ - 1;
+    r.fhist_frames = taps_ > 1 ? taps_ : 0;
     r.nbf = nbf_;
     r.mask = nullptr;
     if (host_mask) {
@@ -633,8 +635,17 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     an.spec = d_spec_;
     char *feat_now = (char *) d_feat_ + (size_t) (taps_ - 1) * feat_frame_bytes_;  // behind the context frames
     an.feat = feat_now;
-    if (taps_ > 1)  // [features of the last taps - 1 frames | this call's]: the front-end reads taps shifted views of it
-        (void) hipMemcpyAsync(d_feat_, d_fhist_, (size_t) (taps_ - 1) * feat_frame_bytes_, hipMemcpyDeviceToDevice, stream_);
+    char *fhist_last = (char *) d_fhist_ + feat_frame_bytes_;  // the last taps_ - 1 frames' features
+    // one-frame calls of a several-frame front-end: the analysis kernel rolls the history itself and writes the frame's features
+    // into its last slot; the front-end reads its taps from there (no copy launches)
+    const bool roll_in_analysis = taps_ > 1 && T == 1 && fuse_front_ && !debug_taps_;
+    if (roll_in_analysis) {
+        an.feat_hist = d_fhist_;
+        an.hist_slots = taps_ - 1;
+        an.feat = (char *) d_fhist_ + (size_t) (taps_ - 1) * feat_frame_bytes_;
+    } else if (taps_ > 1) {  // [features of the last taps - 1 frames | this call's]: the front-end reads taps shifted views of it
+        (void) hipMemcpyAsync(d_feat_, fhist_last, (size_t) (taps_ - 1) * feat_frame_bytes_, hipMemcpyDeviceToDevice, stream_);
+    }
     an.B = B_;
     an.Bpad = Bpad_;
     an.T = T;
@@ -795,9 +806,11 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     };
 
     // front-end: e = features . W_in + b_in
-    if (!front_in_analysis) gemm(kClsGemmHead, nullptr, 0, d_feat_, nbf_, w_in_, b_in_, d_e_, nbh_ * pi_.npb, kHidden, kOutAPlain, taps_);
-    if (taps_ > 1)  // the last taps - 1 frames of [context | call] are the next call's context
-        (void) hipMemcpyAsync(d_fhist_, (char *) d_feat_ + (size_t) T * feat_frame_bytes_, (size_t) (taps_ - 1) * feat_frame_bytes_,
+    if (!front_in_analysis)
+        gemm(kClsGemmHead, nullptr, 0, roll_in_analysis ? d_fhist_ : d_feat_, nbf_, w_in_, b_in_, d_e_, nbh_ * pi_.npb, kHidden, kOutAPlain,
+             taps_);
+    if (taps_ > 1 && !roll_in_analysis)  // the last taps - 1 frames of [context | call] are the next call's context
+        (void) hipMemcpyAsync(fhist_last, (char *) d_feat_ + (size_t) T * feat_frame_bytes_, (size_t) (taps_ - 1) * feat_frame_bytes_,
                               hipMemcpyDeviceToDevice, stream_);
     // One-frame calls through the quad kernel: the narrow head of stage s (271 -> 1, 5, 40) is computed inside stage s + 1's first
     // layer launch instead of in a launch of its own (kns_gruq.hip, kHead): 15 launches per frame step become 12.

@@ -54,6 +54,11 @@ struct AnalysisArgs {
     const float *front_b = nullptr;  // [18 * 16]
     void *front_out = nullptr;       // A-packed [mtiles][9]
     int front_valid = 0;             // columns >= front_valid are zero
+    // optional (one-frame calls, front-end over several frames): `feat` is the LAST slot of a feature history of hist_slots + 1
+    // frames [slot][mtiles][nbf]; before it is written the workgroup rolls its m-tile's history by one frame (slots 1 .. hist_slots
+    // -> 0 .. hist_slots - 1), so that afterwards the slots are the front-end's taps, oldest first -- no copy launches
+    void *feat_hist = nullptr;
+    int hist_slots = 0;
 };
 void launch_analysis(const AnalysisArgs &a, hipStream_t s);
 

@@ -139,6 +139,19 @@ __global__ __launch_bounds__(kFront ? 512 : 256, kFront ? 1 : 3) void analysis_k
     // anywhere a stream would see them, and the loop carries no conditional vector-memory operation
     const int16_t *pcm_row = g.pcm + (size_t) (b < g.B ? b : g.B - 1) * row_len;
 
+    // (one-frame calls of a several-frame front-end) this m-tile's feature history, slots 1 .. hist_slots, on its way to LDS; it
+    // goes back one slot down after the first barrier, when all of it has been read
+    char *hroll = smem + kOffAEnd + 2 * 272 * 4 + (size_t) (kFront ? 2 : 1) * g.nbf * 1024;
+    if (g.feat_hist) {
+        typedef const __attribute__((address_space(1))) void *gptr_t;
+        typedef __attribute__((address_space(3))) void *lptr_t;
+        for (int i = wave; i < g.hist_slots * g.nbf; i += 4) {
+            const int slot = i / g.nbf, kb = i - slot * g.nbf;
+            __builtin_amdgcn_global_load_lds(
+                (gptr_t) ((const uint4 *) g.feat_hist + (((size_t) (slot + 1) * mtiles + mt) * g.nbf + kb) * 64 + lane),
+                (lptr_t) (hroll + i * 1024), 16, 0, 0);
+        }
+    }
     int prev[8], cur[8], nxt[8];
     load_frame(prev, t0 == 0 ? g.hist_in + (size_t) b * kFrame : pcm_row + (size_t) (t0 - 1) * kFrame, c);
     load_frame(cur, pcm_row + (size_t) t0 * kFrame, c);
@@ -152,6 +165,12 @@ __global__ __launch_bounds__(kFront ? 512 : 256, kFront ? 1 : 3) void analysis_k
         for (int i = tid; i < g.nbf * 64; i += 256) z[i] = uint4{0, 0, 0, 0};
     }
     __syncthreads();
+    if (g.feat_hist) {
+        for (int i = tid; i < g.hist_slots * g.nbf * 64; i += 256) {
+            const int slot = i / (g.nbf * 64), w = i - slot * g.nbf * 64;
+            ((uint4 *) g.feat_hist)[((size_t) slot * mtiles + mt) * g.nbf * 64 + w] = ((const uint4 *) hroll)[i];
+        }
+    }
     char *xw;
     const char *xr, *twl_c;
     fft_lane_bases(smem + kOffAXbuf + wave * kFftWaveBytes, smem + kOffATwl, lane, &xw, &xr, &twl_c);
@@ -208,21 +227,24 @@ __global__ __launch_bounds__(kFront ? 512 : 256, kFront ? 1 : 3) void analysis_k
 
 void launch_analysis(const AnalysisArgs &a, hipStream_t s) {
     dim3 grid(a.Bpad / 16, (a.T + a.seg - 1) / a.seg);
-    const size_t lds = kOffAEnd + 2 * 272 * 4 + (size_t) a.nbf * 1024;
+    const size_t roll = a.feat_hist ? (size_t) a.hist_slots * a.nbf * 1024 : 0;  // (one-frame calls: one workgroup per CU is plenty)
+    const size_t lds = kOffAEnd + 2 * 272 * 4 + (size_t) a.nbf * 1024 + roll;
+    auto go = [&](auto kernel, int threads, size_t bytes) {
+        if (bytes > 48 * 1024) (void) hipFuncSetAttribute((const void *) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
+        hipLaunchKernelGGL(kernel, grid, dim3(threads), bytes, s, a);
+    };
     if (a.precision == kBf16) {
-        if (a.front_w && a.T == 1 && a.write_spec) {  // the front-end GEMM inside (one frame: one loop iteration, three barriers)
-            const size_t ldsf = lds + PBF16::NBH * 1024;
-            allow_dynamic_lds(analysis_kernel<PBF16, true, true>, ldsf);
-            hipLaunchKernelGGL((analysis_kernel<PBF16, true, true>), grid, dim3(512), ldsf, s, a);
-        } else if (a.write_spec)
-            hipLaunchKernelGGL((analysis_kernel<PBF16, true, false>), grid, dim3(256), lds, s, a);
+        if (a.front_w && a.T == 1 && a.write_spec && !a.feat_hist)  // the front-end GEMM inside (one frame: one loop iteration, three barriers)
+            go(analysis_kernel<PBF16, true, true>, 512, lds + PBF16::NBH * 1024);
+        else if (a.write_spec)
+            go(analysis_kernel<PBF16, true, false>, 256, lds);
         else
-            hipLaunchKernelGGL((analysis_kernel<PBF16, false, false>), grid, dim3(256), lds, s, a);
+            go(analysis_kernel<PBF16, false, false>, 256, lds);
     } else {
         if (a.write_spec)
-            hipLaunchKernelGGL((analysis_kernel<PF32, true, false>), grid, dim3(256), lds, s, a);
+            go(analysis_kernel<PF32, true, false>, 256, lds);
         else
-            hipLaunchKernelGGL((analysis_kernel<PF32, false, false>), grid, dim3(256), lds, s, a);
+            go(analysis_kernel<PF32, false, false>, 256, lds);
     }
 }
 
