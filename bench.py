@@ -289,11 +289,14 @@ def extra_points(args, torch, np, koala_amd, model, kb, x, dx, dy, base, local_r
     for _ in range(10):
         k5.process_device(T, dx.data_ptr(), dy.data_ptr())
     p5 = k5.profile_read()
+    k5.profile_enable(False)
+    dt1 = time_steps(lambda: k5.process_device(1, d1.data_ptr(), o1.data_ptr()), sync, 300, 30)  # ... and one frame per call
     k5.delete()
     out['front_taps5'] = {'workload': 'KNS-v1.1 (five-frame front-end, random weights), %d streams x %d frames per call, %s' % (B, T, args.precision),
                           'frames_per_s': round(B * T * 100 / dt, 1), 'ms_per_call': round(dt / 100 * 1e3, 4),
                           'mac_per_stream_frame': MAC_GEMM_IN + MAC_GRU + MAC_HEAD + 4 * 257 * H,
-                          'gemm_head_class_ms_per_call': round(p5['gemm_head']['ms'] / 10, 4)}
+                          'gemm_head_class_ms_per_call': round(p5['gemm_head']['ms'] / 10, 4),
+                          'one_frame_per_call_frames_per_s': round(B * 300 / dt1, 1), 'one_frame_per_call_ms': round(dt1 / 300 * 1e3, 4)}
 
     # -- BASELINE configs[1]: 256 streams, fp32 mask network
     for T1 in (32, 1):
