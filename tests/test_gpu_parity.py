@@ -139,6 +139,27 @@ def test_bf16_mask_rms_at_batch_scale(random_model, B, T, calls):
     assert rms < 1e-3, rms
 
 
+@pytest.mark.parametrize('model_kind', ['random', 'random5'])
+def test_full_batch_one_frame_calls_equal_one_long_call(random_model, random5_model, model_kind):
+    """BASELINE configs[2]'s batch, 4 096 distinct streams: eight one-frame calls (the one-step quad kernel with the narrow heads
+    inside, the front-end in the analysis launch and the mask head in the synthesis launch; KNS-v1.1: the feature history rolled
+    by the analysis kernel, the one-frame form of the five-frame front-end) against ONE eight-frame call (input GEMM + recurrent
+    kernel, weight-stationary narrow GEMMs, recomputed spectrum): the same PCM, bit for bit -- a stream's samples do not depend on
+    how its frames were grouped into calls.  Size-independent property: no oracle involved."""
+    model = random_model if model_kind == 'random' else random5_model
+    B, T = 4096, 8
+    x = synth_streams(B, 2 * T, seed=77)
+    ka = koala_amd.create_batch('key', B, T, 'bf16', model_path=model)
+    kb = koala_amd.create_batch('key', B, T, 'bf16', model_path=model)
+    for c in range(2):  # the second round starts from non-trivial state on both sides
+        xc = np.ascontiguousarray(x[:, c * T * 256:(c + 1) * T * 256])
+        whole = ka.process(xc)
+        parts = np.concatenate([kb.process(np.ascontiguousarray(xc[:, t * 256:(t + 1) * 256])) for t in range(T)], axis=1)
+        assert np.array_equal(whole, parts), (c, int(lsb(whole, parts).max()))
+    ka.delete()
+    kb.delete()
+
+
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
 def test_result_does_not_depend_on_batch_slot_or_chunking(random_model, precision):
     x = synth_streams(3, 12, seed=5)
