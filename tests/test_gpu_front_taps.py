@@ -54,7 +54,7 @@ def test_the_context_changes_the_output(random5_model, random_model):
     assert lsb(y1, y2).max() > 50
 
 
-@pytest.mark.parametrize('precision,B,Tmax,calls', [('fp32', 21, 6, 20), ('bf16', 21, 6, 20), ('bf16', 4100, 3, 8)])
+@pytest.mark.parametrize('precision,B,Tmax,calls', [('fp32', 21, 6, 20), ('bf16', 21, 6, 20), ('bf16', 4100, 3, 8), ('bf16', 4096, 3, 10)])
 def test_random_call_sequences_with_resets(random5_model, precision, B, Tmax, calls):
     """The soak of tests/test_gpu_parity.py on the five-frame model: random chunk lengths (1 .. Tmax: shorter and longer than
     the context), host and device pointers, masked and full resets -- the feature history must follow the oracle's."""
