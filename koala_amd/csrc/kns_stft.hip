@@ -19,18 +19,36 @@ constexpr int kOffStftEnd = kOffXbuf + 4 * kFftWaveBytes;
 
 // kSynth: also the synthesis window.  (The analysis kernel leaves that table out and puts its exchange tiles there: 2 KiB
 // decide whether three of its workgroups fit a CU's 160 KiB.)
+// The tables of a workgroup, requested by its 256 STFT threads in ONE go and stored to LDS when they are there (as loops of
+// load -> store, hipcc waited for every load before the next one was requested: five memory round trips at the head of every
+// launch, most of a one-frame call's STFT kernels).
+struct StftTables {
+    float2 tw[2];
+    float win[2];
+    float2 twl;
+};
+__device__ __forceinline__ void stft_request_tables(StftTables &t, const float *twiddle, const float *window, int tid) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        t.tw[q] = ((const float2 *) twiddle)[tid + 256 * q];
+        t.win[q] = window[tid + 256 * q];
+    }
+    t.twl = ((const float2 *) twiddle)[2 * (((tid & 15) * (tid >> 4)) & 255)];  // fft_fill_twiddles' entry of this thread
+}
 template <bool kSynth>
-__device__ __forceinline__ void stft_load_tables(char *smem, const float *twiddle, const float *window, int tid) {
+__device__ __forceinline__ void stft_store_tables(const StftTables &t, char *smem, int tid) {
     float2 *tw = (float2 *) (smem + kOffTw);
     float *win = (float *) (smem + kOffWin), *wins = (float *) (smem + kOffWinS);
-    for (int i = tid; i < 512; i += 256) {
-        tw[i] = ((const float2 *) twiddle)[i];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = tid + 256 * q;
+        tw[i] = t.tw[q];
         // the powers of two of the spec's (x / 32768) w and (y / 256) w are folded into the window: exact, so the
         // products are the spec's bit for bit
-        win[i] = window[i] * (1.0f / 32768.0f);
-        if (kSynth) wins[i] = window[i] * (1.0f / 256.0f);
+        win[i] = t.win[q] * (1.0f / 32768.0f);
+        if (kSynth) wins[i] = t.win[q] * (1.0f / 256.0f);
     }
-    fft_fill_twiddles(smem + (kSynth ? kOffTwl : kOffWinS), (const float2 *) twiddle, tid, 256);
+    ((float2 *) (smem + (kSynth ? kOffTwl : kOffWinS)))[tid] = t.twl;
 }
 // analysis kernel: [tw | win | fft twiddles | exchange tiles | mean, scale | feature tile]
 constexpr int kOffATwl = kOffWinS, kOffAXbuf = kOffATwl + kFftTwiddleBytes, kOffAEnd = kOffAXbuf + 4 * kFftWaveBytes;
@@ -155,10 +173,23 @@ __global__ __launch_bounds__(kFront ? 512 : 256, kFront ? 1 : 3) void analysis_k
     int prev[8], cur[8], nxt[8];
     load_frame(prev, t0 == 0 ? g.hist_in + (size_t) b * kFrame : pcm_row + (size_t) (t0 - 1) * kFrame, c);
     load_frame(cur, pcm_row + (size_t) t0 * kFrame, c);
-    stft_load_tables<false>(smem, g.twiddle, g.window, tid);
-    for (int i = tid; i < kBins; i += 256) {
-        lmean[i] = g.mean[i];
-        lscale[i] = g.scale[i];
+    StftTables tbl;
+    stft_request_tables(tbl, g.twiddle, g.window, tid);
+    float ms[2][2];  // mean, scale of bins tid and tid + 256 (clamped: 257 bins)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = tid + 256 * q < kBins ? tid + 256 * q : kBins - 1;
+        ms[q][0] = g.mean[i];
+        ms[q][1] = g.scale[i];
+    }
+    stft_store_tables<false>(tbl, smem, tid);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = tid + 256 * q;
+        if (i < kBins) {
+            lmean[i] = ms[q][0];
+            lscale[i] = ms[q][1];
+        }
     }
     {
         uint4 *z = (uint4 *) tile;
@@ -365,7 +396,9 @@ __global__ __launch_bounds__(kMaskIn ? 512 : 256, kMaskIn ? 1 : 3) void synthesi
         if (!kMaskIn) mask_fetch(mk, tb);
         spec_fetch(xs, tb);
     }
-    stft_load_tables<true>(smem, g.twiddle, g.window, tid);
+    StftTables tbl;
+    stft_request_tables(tbl, g.twiddle, g.window, tid);
+    stft_store_tables<true>(tbl, smem, tid);
     __syncthreads();
     char *xw;
     const char *xr, *twl_c;
