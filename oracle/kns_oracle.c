@@ -137,7 +137,7 @@ struct kns_params {
     float *mean, *scale, *w_in, *b_in;
     kns_stage_t st[KNS_STAGES];
     float window[KNS_NFFT];
-    float tw_re[KNS_NFFT / 2], tw_im[KNS_NFFT / 2]; /* exp(-2 pi i k / 512) */
+    float tw_re[KNS_NFFT], tw_im[KNS_NFFT]; /* exp(-2 pi i k / 512), k = 0..511 */
 };
 
 static void round_weights(float *w, size_t n) {
@@ -153,6 +153,17 @@ static void round_weights(float *w, size_t n) {
 static void scale_gates(float *w, size_t rows) {
     for (size_t r = 0; r < rows; ++r)
         for (int c = 0; c < KNS_G3; ++c) w[r * KNS_G3 + c] = w[r * KNS_G3 + c] * (c < 2 * KNS_H ? KNS_GATE_SCALE_RZ : KNS_GATE_SCALE_N);
+}
+
+/* the two tables of the transform: double-precision sine / cosine rounded once to fp32 (the engine builds the same ones on
+ * the host, kns_engine.cpp Engine::init) */
+static void tables_init(kns_params_t *p) {
+    const double pi = 3.14159265358979323846;
+    for (int n = 0; n < KNS_NFFT; ++n) {
+        p->window[n] = (float) sin(pi * (double) n / KNS_NFFT);
+        p->tw_re[n] = (float) cos(2.0 * pi * (double) n / KNS_NFFT);
+        p->tw_im[n] = (float) -sin(2.0 * pi * (double) n / KNS_NFFT);
+    }
 }
 
 int kns_params_load(const char *path, int precision, kns_params_t **out) {
@@ -227,12 +238,7 @@ int kns_params_load(const char *path, int precision, kns_params_t **out) {
     }
 #undef TAKE_GRU
 #undef TAKE
-    const double pi = 3.14159265358979323846;
-    for (int n = 0; n < KNS_NFFT; ++n) p->window[n] = (float) sin(pi * (double) n / KNS_NFFT);
-    for (int k = 0; k < KNS_NFFT / 2; ++k) {
-        p->tw_re[k] = (float) cos(2.0 * pi * (double) k / KNS_NFFT);
-        p->tw_im[k] = (float) -sin(2.0 * pi * (double) k / KNS_NFFT);
-    }
+    tables_init(p);
     *out = p;
     return 0;
 }
@@ -248,7 +254,160 @@ int kns_oracle_delay_sample(void) { return KNS_FRAME; }
 
 /* ------------------------------------------------------------------------------------------------ FFT-512 */
 
-/* in-place iterative radix-2 DIT, forward (exp(-i..)) when inverse==0; unnormalised both ways */
+/* The spec's transform is the packed real FFT-512 the way the GPU evaluates it, operation for
+ * operation, so that the fp32 configuration is comparable bit for bit:
+ *
+ *   z[n] = x[2n] + i x[2n+1]                                   (256 complex points)
+ *   Z    = FFT-256(z),  256 = 16 x 16:  DFT-16 over n = 16 j + c (j = 0..15) for every column c,
+ *                                        times W_256^(c k1), transpose, DFT-16 over the columns  ->  Z[k1 + 16 k2]
+ *   X[k] = ((Z[k] + conj Z[256-k]) - i W_512^k (Z[k] - conj Z[256-k])) / 2,  X[0] = Re Z[0] + Im Z[0],  X[256] = Re Z[0] - Im Z[0]
+ *
+ * with the DFT-16 as two radix-4 levels (kns_dft16) and every complex product as kns_cmul.  The inverse runs the same
+ * FFT-256 with real and imaginary parts swapped.  The device code this mirrors: koala_amd/csrc/kns_device.hpp (radix4, dft16,
+ * cmul, fft256_rows) and kns_stft.hip (real_spectrum, synthesis_kernel).  The textbook radix-2 transform further down is
+ * kept as an independent cross-check to a tolerance (tests/test_oracle.py), it is not part of the spec any more. */
+
+typedef struct {
+    float x, y;
+} kns_cpx;
+
+static inline kns_cpx kns_cadd(kns_cpx a, kns_cpx b) { return (kns_cpx){a.x + b.x, a.y + b.y}; }
+static inline kns_cpx kns_csub(kns_cpx a, kns_cpx b) { return (kns_cpx){a.x - b.x, a.y - b.y}; }
+/* a w: each part one product and one fused multiply-add */
+static inline kns_cpx kns_cmul(kns_cpx a, kns_cpx w) {
+    return (kns_cpx){fmaf(a.x, w.x, a.y * -w.y), fmaf(a.x, w.y, a.y * w.x)};
+}
+
+/* 4-point DFT, natural order in and out, W = -i */
+static inline void kns_radix4(kns_cpx *v) {
+    const kns_cpx a0 = kns_cadd(v[0], v[2]), a1 = kns_csub(v[0], v[2]), a2 = kns_cadd(v[1], v[3]), d = kns_csub(v[1], v[3]);
+    const kns_cpx a3 = {d.y, -d.x}; /* (v1 - v3) (-i) */
+    v[0] = kns_cadd(a0, a2);
+    v[1] = kns_cadd(a1, a3);
+    v[2] = kns_csub(a0, a2);
+    v[3] = kns_csub(a1, a3);
+}
+
+/* 16-point DFT, natural order in and out: four radix-4 over the points b, b + 4, b + 8, b + 12, the twiddles W_16^(b c)
+ * (multiples of pi/4 written out as sums and differences times sqrt(1/2)), four radix-4 across */
+static void kns_dft16(kns_cpx *x) {
+    const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, c2 = 0.70710678118654752f;
+    kns_cpx u[4][4];
+    for (int b = 0; b < 4; ++b) {
+        kns_cpx q[4] = {x[b], x[4 + b], x[8 + b], x[12 + b]};
+        kns_radix4(q);
+        for (int c = 0; c < 4; ++c) u[b][c] = q[c];
+    }
+    kns_cpx t;
+    u[1][1] = kns_cmul(u[1][1], (kns_cpx){c1, -s1});
+    t = u[1][2];
+    u[1][2] = (kns_cpx){(t.x + t.y) * c2, (t.y - t.x) * c2};
+    u[1][3] = kns_cmul(u[1][3], (kns_cpx){s1, -c1});
+    t = u[2][1];
+    u[2][1] = (kns_cpx){(t.x + t.y) * c2, (t.y - t.x) * c2};
+    t = u[2][2];
+    u[2][2] = (kns_cpx){t.y, -t.x};
+    t = u[2][3];
+    u[2][3] = (kns_cpx){(t.y - t.x) * c2, -((t.x + t.y) * c2)};
+    u[3][1] = kns_cmul(u[3][1], (kns_cpx){s1, -c1});
+    t = u[3][2];
+    u[3][2] = (kns_cpx){(t.y - t.x) * c2, -((t.x + t.y) * c2)};
+    u[3][3] = kns_cmul(u[3][3], (kns_cpx){-c1, s1});
+    for (int c = 0; c < 4; ++c) {
+        kns_cpx q[4] = {u[0][c], u[1][c], u[2][c], u[3][c]};
+        kns_radix4(q);
+        for (int d = 0; d < 4; ++d) x[c + 4 * d] = q[d];
+    }
+}
+
+/* forward FFT-256, natural order in and out; W_256^m = tw[2 m] of the 512-point table */
+static void kns_fft256(const kns_params_t *p, const kns_cpx *z, kns_cpx *Z) {
+    kns_cpx tile[16][16], v[16];
+    for (int c = 0; c < 16; ++c) {
+        for (int j = 0; j < 16; ++j) v[j] = z[16 * j + c];
+        kns_dft16(v);
+        for (int k1 = 1; k1 < 16; ++k1) {
+            const int m = 2 * ((c * k1) & 255);
+            v[k1] = kns_cmul(v[k1], (kns_cpx){p->tw_re[m], p->tw_im[m]});
+        }
+        for (int k1 = 0; k1 < 16; ++k1) tile[k1][c] = v[k1];
+    }
+    for (int k1 = 0; k1 < 16; ++k1) {
+        for (int j = 0; j < 16; ++j) v[j] = tile[k1][j];
+        kns_dft16(v);
+        for (int k2 = 0; k2 < 16; ++k2) Z[k1 + 16 * k2] = v[k2];
+    }
+}
+
+/* half spectrum X[0..256] of the windowed block [hist | pcm] */
+static void spectrum512(const kns_params_t *p, const int16_t *hist, const int16_t *pcm, float *spec) {
+    kns_cpx z[256], Z[256];
+    for (int n = 0; n < 256; ++n) {
+        const int16_t *src = n < 128 ? hist + 2 * n : pcm + 2 * n - KNS_FRAME;
+        z[n].x = ((float) src[0] * (1.0f / 32768.0f)) * p->window[2 * n];
+        z[n].y = ((float) src[1] * (1.0f / 32768.0f)) * p->window[2 * n + 1];
+    }
+    kns_fft256(p, z, Z);
+    for (int k = 1; k < 256; ++k) {
+        const kns_cpx zk = Z[k], zp = Z[256 - k];
+        const kns_cpx s = {zk.x + zp.x, zk.y - zp.y}, d = {zk.x - zp.x, zk.y + zp.y};
+        const kns_cpx q = kns_cmul(d, (kns_cpx){p->tw_re[k], p->tw_im[k]});
+        spec[2 * k] = 0.5f * (s.x + q.y);
+        spec[2 * k + 1] = 0.5f * (s.y - q.x);
+    }
+    spec[0] = Z[0].x + Z[0].y; /* DC and Nyquist of a real signal are real */
+    spec[1] = 0.0f;
+    spec[2 * 256] = Z[0].x - Z[0].y;
+    spec[2 * 256 + 1] = 0.0f;
+}
+
+static void analysis(const kns_params_t *p, const int16_t *hist, const int16_t *pcm, float *spec, float *feat) {
+    spectrum512(p, hist, pcm, spec);
+    for (int k = 0; k < KNS_BINS; ++k) {
+        const float re = spec[2 * k], im = spec[2 * k + 1];
+        float pw = fmaf(re, re, im * im);
+        if (k == 0 || k == KNS_BINS - 1) pw = re * re;
+        feat[k] = (kns_log(pw + 1e-10f) - p->mean[k]) * p->scale[k];
+    }
+}
+
+static void synthesis(const kns_params_t *p, const float *spec, const float *mask, float *tail, int16_t *out) {
+    kns_cpx y[256], v[256], V[256];
+    for (int k = 0; k < 256; ++k) y[k] = (kns_cpx){mask[k] * spec[2 * k], mask[k] * spec[2 * k + 1]};
+    for (int k = 0; k < 256; ++k) {
+        kns_cpx yk = y[k], yq = y[(256 - k) & 255]; /* Y[k], Y[256 - k] */
+        if (k == 0) {
+            yk = (kns_cpx){mask[0] * spec[0], 0.0f};
+            yq = (kns_cpx){mask[256] * spec[2 * 256], 0.0f};
+        }
+        /* e = Y[k] + conj Y[256 - k], d = Y[k] - conj Y[256 - k], o = conj(W_512^k) d; the packed sequence's spectrum is
+         * (e + i o) / 2, and it enters the FORWARD transform with its parts swapped (= the inverse transform, parts swapped) */
+        const kns_cpx e = {yk.x + yq.x, yk.y - yq.y}, d = {yk.x - yq.x, yk.y + yq.y};
+        const kns_cpx o = kns_cmul(d, (kns_cpx){p->tw_re[k], -p->tw_im[k]});
+        const float zr = 0.5f * (e.x - o.y), zi = 0.5f * (e.y + o.x);
+        v[k] = (kns_cpx){zi, zr};
+    }
+    kns_fft256(p, v, V);
+    for (int n = 0; n < 256; ++n) {
+        const float y0 = V[n].y * (p->window[2 * n] * (1.0f / 256.0f)), y1 = V[n].x * (p->window[2 * n + 1] * (1.0f / 256.0f));
+        if (n < 128) {
+            float a0 = (tail[2 * n] + y0) * 32768.0f, a1 = (tail[2 * n + 1] + y1) * 32768.0f;
+            a0 = fminf(fmaxf(roundf(a0), -32768.0f), 32767.0f); /* half away from zero, saturated */
+            a1 = fminf(fmaxf(roundf(a1), -32768.0f), 32767.0f);
+            out[2 * n] = (int16_t) a0;
+            out[2 * n + 1] = (int16_t) a1;
+        } else {
+            v[n] = (kns_cpx){y0, y1};
+        }
+    }
+    for (int n = 128; n < 256; ++n) {
+        tail[2 * n - KNS_FRAME] = v[n].x;
+        tail[2 * n - KNS_FRAME + 1] = v[n].y;
+    }
+}
+
+/* ---- the textbook statement (in-place iterative radix-2 DIT over 512 complex points), NOT the spec: an independent
+ * cross-check of the transform above to a tolerance (kns_oracle_analysis_radix2 / kns_oracle_synthesis_radix2) */
 static void fft512(const kns_params_t *p, float *re, float *im, int inverse) {
     for (int i = 0, j = 0; i < KNS_NFFT; ++i) {
         if (i < j) {
@@ -282,7 +441,7 @@ static void fft512(const kns_params_t *p, float *re, float *im, int inverse) {
     }
 }
 
-static void analysis(const kns_params_t *p, const int16_t *hist, const int16_t *pcm, float *spec, float *feat) {
+static void analysis_radix2(const kns_params_t *p, const int16_t *hist, const int16_t *pcm, float *spec, float *feat) {
     float re[KNS_NFFT], im[KNS_NFFT];
     for (int n = 0; n < KNS_FRAME; ++n) {
         re[n] = ((float) hist[n] * (1.0f / 32768.0f)) * p->window[n];
@@ -296,11 +455,11 @@ static void analysis(const kns_params_t *p, const int16_t *hist, const int16_t *
         float pw = fmaf(re[k], re[k], im[k] * im[k]);
         feat[k] = (kns_log(pw + 1e-10f) - p->mean[k]) * p->scale[k];
     }
-    spec[1] = 0.0f; /* DC and Nyquist of a real signal are real */
+    spec[1] = 0.0f;
     spec[2 * (KNS_BINS - 1) + 1] = 0.0f;
 }
 
-static void synthesis(const kns_params_t *p, const float *spec, const float *mask, float *tail, int16_t *out) {
+static void synthesis_radix2(const kns_params_t *p, const float *spec, const float *mask, float *tail, int16_t *out) {
     float re[KNS_NFFT], im[KNS_NFFT];
     for (int k = 0; k < KNS_BINS; ++k) {
         re[k] = spec[2 * k] * mask[k];
@@ -317,7 +476,7 @@ static void synthesis(const kns_params_t *p, const float *spec, const float *mas
         float y0 = (re[n] * (1.0f / KNS_NFFT)) * p->window[n];
         float y1 = (re[n + KNS_FRAME] * (1.0f / KNS_NFFT)) * p->window[n + KNS_FRAME];
         float v = (tail[n] + y0) * 32768.0f;
-        v = roundf(v); /* half away from zero */
+        v = roundf(v);
         v = fminf(fmaxf(v, -32768.0f), 32767.0f);
         out[n] = (int16_t) v;
         tail[n] = y1;
@@ -653,18 +812,26 @@ void kns_oracle_analysis(const kns_params_t *p, const int16_t *hist, const int16
     analysis(p, hist, pcm, spectrum, features);
 }
 
-void kns_oracle_synthesis(const float *spectrum, const float *mask, float *tail, int16_t *out) {
+static const kns_params_t *table_params(void) {
     /* window/twiddles do not depend on the parameter file; build a table-only params once */
     static kns_params_t tp;
     static int init = 0;
     if (!init) {
-        const double pi = 3.14159265358979323846;
-        for (int n = 0; n < KNS_NFFT; ++n) tp.window[n] = (float) sin(pi * (double) n / KNS_NFFT);
-        for (int k = 0; k < KNS_NFFT / 2; ++k) {
-            tp.tw_re[k] = (float) cos(2.0 * pi * (double) k / KNS_NFFT);
-            tp.tw_im[k] = (float) -sin(2.0 * pi * (double) k / KNS_NFFT);
-        }
+        tables_init(&tp);
         init = 1;
     }
-    synthesis(&tp, spectrum, mask, tail, out);
+    return &tp;
+}
+
+void kns_oracle_synthesis(const float *spectrum, const float *mask, float *tail, int16_t *out) {
+    synthesis(table_params(), spectrum, mask, tail, out);
+}
+
+void kns_oracle_analysis_radix2(const kns_params_t *p, const int16_t *hist, const int16_t *pcm, float *spectrum,
+                                float *features) {
+    analysis_radix2(p, hist, pcm, spectrum, features);
+}
+
+void kns_oracle_synthesis_radix2(const float *spectrum, const float *mask, float *tail, int16_t *out) {
+    synthesis_radix2(table_params(), spectrum, mask, tail, out);
 }

@@ -85,6 +85,11 @@ void kns_oracle_analysis(const kns_params_t *p, const int16_t *hist256, const in
                          float *spectrum /*[257][2]*/, float *features /*[257]*/);
 void kns_oracle_synthesis(const float *spectrum /*[257][2]*/, const float *mask /*[257]*/, float *tail256 /*in/out*/,
                           int16_t *out256);
+/* the same two stages through a textbook radix-2 FFT-512 over the full complex block: NOT the spec (whose operation order
+ * is the packed 16 x 16 transform of kns_oracle.c), an independent cross-check to a tolerance */
+void kns_oracle_analysis_radix2(const kns_params_t *p, const int16_t *hist256, const int16_t *pcm256, float *spectrum,
+                                float *features);
+void kns_oracle_synthesis_radix2(const float *spectrum, const float *mask, float *tail256, int16_t *out256);
 /* scalar math of the spec (exposed so tests can compare the GPU's device functions bit for bit) */
 float kns_exp(float x);
 float kns_log(float x);

@@ -15,7 +15,8 @@ from conftest import synth_streams
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
-BF16_TOL = int(os.environ.get('KOALA_TEST_BF16_TOL', '5'))
+BF16_TOL = 5   # (a constant: tests/test_gpu_parity.py)
+FP32_TOL = 0   # fp32 engine = fp32 oracle, sample for sample
 
 
 def lsb(a, b):
@@ -32,7 +33,7 @@ def test_five_frame_front_end_matches_the_oracle(random5_model, precision, B, T,
     for c in range(calls):
         xc = np.ascontiguousarray(x[:, c * T * 256:(c + 1) * T * 256])
         d = lsb(kb.process(xc), ref.process(xc))
-        assert d.max() <= (BF16_TOL if precision == 'bf16' else 1), (c, int(d.max()))
+        assert d.max() <= (BF16_TOL if precision == 'bf16' else FP32_TOL), (c, int(d.max()))
     kb.delete()
 
 
@@ -61,7 +62,7 @@ def test_random_call_sequences_with_resets(random5_model, precision, B, Tmax, ca
     torch = pytest.importorskip('torch')
     rng = np.random.default_rng(7)
     prec = oracle.PREC_BF16 if precision == 'bf16' else oracle.PREC_FP32
-    tol = BF16_TOL if precision == 'bf16' else 1
+    tol = BF16_TOL if precision == 'bf16' else FP32_TOL
     kb = koala_amd.create_batch('key', B, Tmax, precision, model_path=random5_model)
     ref = oracle.Oracle(random5_model, B, prec)
     for call in range(calls):
@@ -94,11 +95,11 @@ def test_single_stream_abi_with_the_five_frame_model(random5_model, test_pcm):
     k = koala_amd.create('key', model_path=random5_model, device='gpu:0')
     ref = oracle.Oracle(random5_model, 1)
     out = np.concatenate([np.array(k.process(test_pcm[i:i + 256]), np.int16) for i in range(0, n, 256)])
-    assert lsb(out, ref.process(test_pcm[:n])).max() <= 1
+    assert np.array_equal(out, ref.process(test_pcm[:n]))
     k.reset()
     ref.reset()
     out = np.concatenate([np.array(k.process(test_pcm[i:i + 256]), np.int16) for i in range(n, 2 * n, 256)])
-    assert lsb(out, ref.process(test_pcm[n:2 * n])).max() <= 1
+    assert np.array_equal(out, ref.process(test_pcm[n:2 * n]))
     k.delete()
 
 
@@ -112,16 +113,14 @@ def test_imported_reference_model_runs_on_the_gpu_like_on_the_oracle(test_pcm, n
     five front-end taps), converted in the build container: GPU = oracle.  Says nothing about parity with the reference ENGINE
     (fixed-point conventions unknown, profiles/r03_pv_import_search.json)."""
     p = IMPORTED
-    n = 60 * 256
+    n = len(test_pcm) // 256 * 256  # all 365 frames of the reference's fixtures
     x = np.stack([test_pcm[:n], noise_pcm[:n], (test_pcm[:n].astype(int) + noise_pcm[:n]).astype(np.int16)])
-    kb = koala_amd.create_batch('key', 3, 20, 'fp32', model_path=p)
-    y = np.concatenate([kb.process(np.ascontiguousarray(x[:, i:i + 20 * 256])) for i in range(0, n, 20 * 256)], axis=1)
+    kb = koala_amd.create_batch('key', 3, 73, 'fp32', model_path=p)
+    y = np.concatenate([kb.process(np.ascontiguousarray(x[:, i:i + 73 * 256])) for i in range(0, n, 73 * 256)], axis=1)
     kb.delete()
-    d = lsb(y, oracle.Oracle(p, 3).process(x)).reshape(3, 60, 256).max(axis=(0, 2))
-    print('imported .pv model, fp32, max |GPU - oracle| per frame:', d.tolist())
-    # The first frames agree to the LSB (five-frame context, every layer, every tap exercised).  Later the two drift apart (measured:
-    # up to ~125 LSB by frame 60): under this reading of the file's fixed-point conventions the network is not contractive and
-    # amplifies the 1e-6 relative differences between the two FFTs frame after frame -- one more sign that the reading is not the
-    # reference's (with random or hand-built weights of the same topology the outputs stay within 1 LSB for good).
-    assert d[:16].max() <= 1, d.tolist()
-    assert d.max() <= 2000
+    # Under this reading of the file's fixed-point conventions the network is not contractive: it amplifies any difference frame
+    # after frame (round 3, when the oracle's FFT was a textbook radix-2 and the GPU's the 16 x 16 form: 1e-6 relative in the
+    # spectrum grew to ~125 LSB by frame 60).  With the transform part of the spec, operation for operation, there is no
+    # difference to amplify: 0 LSB over all 365 frames of test / noise / mixed.
+    want = oracle.Oracle(p, 3).process(x)
+    assert np.array_equal(y, want), lsb(y, want).reshape(3, -1, 256).max(axis=(0, 2)).tolist()

@@ -2,9 +2,10 @@
 Parity of the HIP engine (through the C ABI of libpv_koala.so) with the CPU oracle on a real MI355X.
 
 Bars (BASELINE.json north_star / DESIGN.md section 5):
-  fp32 engine : int16 PCM within +-1 LSB of the fp32 oracle; spectrum/feature/mask taps within 2e-5 / 1e-4 / 2e-5
-  bf16 engine : mask within 1e-3 RMS of the fp32 oracle; PCM within 4 LSB of the oracle run with the same
-                rounding points (bf16 GEMM operands, fp16 pre-activations), >= 99 % of samples within 1 LSB
+  fp32 engine : IDENTICAL to the fp32 oracle -- int16 PCM and the spectrum / feature / embedding / mask / hidden-state taps, value
+                for value (since round 4 the spec's FFT is the transform the kernels evaluate, operation for operation)
+  bf16 engine : mask within 1e-3 RMS of the fp32 oracle; PCM within 5 LSB of the oracle run with the same
+                rounding points (bf16 GEMM operands, fp16 pre-activations), >= 99.9 % of samples within 1 LSB
 Size-independent properties are checked at BASELINE's full batch (4096 streams).
 """
 import numpy as np
@@ -16,13 +17,16 @@ from oracle import oracle
 
 pytestmark = pytest.mark.gpu
 
-import os as _os
 # bf16 engine vs the oracle with the same rounding points: the two differ only in the gate / head / log transcendentals
 # (hardware v_exp / v_rcp / v_log against the spec's polynomials).  Largest difference ever measured in this suite: see
 # DESIGN.md section 5.
 # Bar 5 LSB (the same as __graft_entry__.smoke(), whose white-noise sample measures 4; this suite's own maximum is 3) plus the
-# distribution checked wherever a histogram is taken: >= 99 % of the samples within 1 LSB.
-BF16_TOL = int(_os.environ.get('KOALA_TEST_BF16_TOL', '5'))
+# distribution checked wherever a histogram is taken: >= 99.9 % of the samples within 1 LSB (measured: 99.99 %).
+# A constant, not a knob: nothing in the environment can loosen it.
+BF16_TOL = 5
+BF16_WITHIN_1 = 0.999
+# fp32 engine: the oracle's values, every one of them
+FP32_TOL = 0
 # the -DKNS_DEV build of the same sources: the only library that reads the KOALA_AMD_* developer switches
 DEV_LIB = koala_amd.developer_library_path()
 
@@ -50,18 +54,16 @@ def test_fp32_stage_taps_and_pcm(random_model, monkeypatch, B, T, calls):
         for b in range(B):
             for t in range(T):
                 ref, tp = streams[b].process_tap(xc[b, t * 256:(t + 1) * 256])
-                assert np.max(np.abs(taps['spectrum'][t, b] - tp['spectrum'])) < 2e-5
-                assert np.max(np.abs(taps['features'][t, b] - tp['features'])) < 1e-4
-                assert np.max(np.abs(taps['embed'][t, b] - tp['embed'])) < 2e-5
-                assert np.max(np.abs(taps['mask'][t, b] - tp['mask'])) < 2e-5
-                assert lsb(ref, y[b, t * 256:(t + 1) * 256]).max() <= 1
-            assert np.max(np.abs(hidden[:, b] - tp['hidden'])) < 2e-5
+                for k in ('spectrum', 'features', 'embed', 'mask'):
+                    assert np.array_equal(taps[k][t, b], tp[k]), (k, c, b, t, float(np.abs(taps[k][t, b] - tp[k]).max()))
+                assert np.array_equal(ref, y[b, t * 256:(t + 1) * 256])
+            assert np.array_equal(hidden[:, b], tp['hidden'])
     kb.delete()
 
 
 @pytest.mark.parametrize('name', ['test', 'noise', 'mixed'])
 def test_fp32_single_stream_abi_on_reference_wavs(gate_model, random_model, test_pcm, noise_pcm, name):
-    """pv_koala_init/process (the reference ABI, one frame per call) on resources/audio_samples: +-1 LSB."""
+    """pv_koala_init/process (the reference ABI, one frame per call) on resources/audio_samples: the oracle's samples, all of them."""
     pcm = {'test': test_pcm, 'noise': noise_pcm,
            'mixed': (test_pcm.astype(int) + noise_pcm).astype(np.int16)}[name]
     n = len(pcm) // 256 * 256
@@ -70,9 +72,7 @@ def test_fp32_single_stream_abi_on_reference_wavs(gate_model, random_model, test
         out = np.concatenate([np.array(k.process(pcm[i:i + 256]), np.int16) for i in range(0, n, 256)])
         k.delete()
         ref = run_oracle(model, pcm[None, :n])[0]
-        d = lsb(out, ref)
-        assert d.max() <= 1
-        assert (d == 0).mean() > 0.97
+        assert np.array_equal(out, ref), int(lsb(out, ref).max())
 
 
 def test_bf16_against_both_oracles(random_model, test_pcm):
@@ -96,7 +96,7 @@ def test_bf16_against_both_oracles(random_model, test_pcm):
     d = lsb(out, run_oracle(random_model, x, oracle.PREC_BF16))
     hist = np.bincount(np.minimum(d.ravel(), 8), minlength=9)
     print('bf16 engine vs bf16-rounding oracle, |diff| histogram 0..8+:', hist.tolist(), 'mask rms vs fp32:', rms)
-    assert d.max() <= BF16_TOL and (d == 0).mean() > 0.75 and (d <= 1).mean() > 0.99
+    assert d.max() <= BF16_TOL and (d == 0).mean() > 0.75 and (d <= 1).mean() > BF16_WITHIN_1
     assert lsb(out, run_oracle(random_model, x)).max() <= 24  # against the unrounded oracle
 
 
@@ -289,7 +289,7 @@ def test_full_batch_matches_oracle_on_sampled_streams(random_model):
     y = kb.process(x)
     kb.delete()
     ref = run_oracle(random_model, base)
-    assert lsb(y[:64], ref).max() <= 1
+    assert np.array_equal(y[:64], ref)
     for blk in range(1, B // 64):  # every replica of the 64 inputs is bit-identical, whatever its slot
         assert np.array_equal(y[blk * 64:(blk + 1) * 64], y[:64])
 
@@ -319,7 +319,7 @@ def test_ragged_large_batches_take_the_fallback_kernels(random_model, precision,
     o = oracle.Oracle(random_model, 8, oracle.PREC_BF16 if precision == 'bf16' else oracle.PREC_FP32)
     ref = np.concatenate([o.process(base), o.process(base)], axis=1)
     got = np.concatenate([y[:8], y2[:8]], axis=1)
-    assert lsb(got, ref).max() <= (BF16_TOL if precision == 'bf16' else 1)
+    assert lsb(got, ref).max() <= (BF16_TOL if precision == 'bf16' else FP32_TOL)
 
 
 @pytest.mark.parametrize('kind', ['random', 'gate', 'adaptive'])
@@ -330,7 +330,7 @@ def test_against_committed_golden_vectors(kind):
     from conftest import GOLDEN
     g = np.load(os.path.join(GOLDEN, 'kns_v1_golden.npz'))
     model = model_file(kind)
-    for precision, tol in (('fp32', 1), ('bf16', BF16_TOL)):
+    for precision, tol in (('fp32', FP32_TOL), ('bf16', BF16_TOL)):
         kb = koala_amd.create_batch('key', 3, 16, precision, model_path=model)
         y = np.concatenate([kb.process(np.ascontiguousarray(g['pcm'][:, c * 4096:(c + 1) * 4096])) for c in range(3)], axis=1)
         kb.delete()
@@ -404,7 +404,7 @@ def test_random_call_sequences_keep_the_stream_state_straight(random_model, prec
     torch = pytest.importorskip('torch')
     rng = np.random.default_rng(42)
     prec = oracle.PREC_BF16 if precision == 'bf16' else oracle.PREC_FP32
-    tol = BF16_TOL if precision == 'bf16' else 1
+    tol = BF16_TOL if precision == 'bf16' else FP32_TOL
     kb = koala_amd.create_batch('key', B, Tmax, precision, model_path=random_model)
     ref = oracle.Oracle(random_model, B, prec)
     worst = 0
@@ -446,7 +446,7 @@ def test_long_chunks_of_small_and_odd_batches(random_model, precision, B, T):
     kb.delete()
     ref = oracle.Oracle(random_model, B, oracle.PREC_BF16 if precision == 'bf16' else oracle.PREC_FP32)
     want, want2 = ref.process(x), ref.process(x)
-    tol = BF16_TOL if precision == 'bf16' else 1
+    tol = BF16_TOL if precision == 'bf16' else FP32_TOL
     assert lsb(y, want).max() <= tol and lsb(y2, want2).max() <= tol
 
 
@@ -482,8 +482,8 @@ def test_distinct_handles_on_distinct_threads(random_model):
     for t in threads:
         t.join()
     assert not errors, errors
-    assert lsb(results['b32'], want['fp32']).max() <= 1 and lsb(results['b16'], want['bf16']).max() <= BF16_TOL
-    assert lsb(results['s0'], want['fp32'][0]).max() <= 1 and lsb(results['s5'], want['fp32'][5]).max() <= 1
+    assert np.array_equal(results['b32'], want['fp32']) and lsb(results['b16'], want['bf16']).max() <= BF16_TOL
+    assert np.array_equal(results['s0'], want['fp32'][0]) and np.array_equal(results['s5'], want['fp32'][5])
 
 
 @pytest.mark.parametrize('precision,B,T', [('bf16', 32768, 16), ('bf16', 20000, 8), ('fp32', 12288, 4)])
@@ -499,7 +499,7 @@ def test_batches_far_beyond_the_bench_size(random_model, precision, B, T):
         chunk = np.ascontiguousarray(base[:, c * T * 256:(c + 1) * T * 256])
         y = kb.process(np.tile(chunk, (reps, 1))[:B])
         want = ref.process(chunk)
-        assert lsb(y[:64], want).max() <= (BF16_TOL if precision == 'bf16' else 1)
+        assert lsb(y[:64], want).max() <= (BF16_TOL if precision == 'bf16' else FP32_TOL)
         full = (B // 64) * 64
         assert np.array_equal(y[:full].reshape(B // 64, 64, -1), np.broadcast_to(y[:64], (B // 64, 64, y.shape[1])))
         if B > full:
@@ -566,7 +566,7 @@ def test_baseline_config1_b256_fp32_at_its_stated_size(random_model, T, calls):
     for c in range(calls):
         xc = np.ascontiguousarray(x[:, c * T * 256:(c + 1) * T * 256])
         d = lsb(kb.process(xc), ref.process(xc))
-        assert d.max() <= 1 and (d == 0).mean() > 0.97, (c, int(d.max()))
+        assert d.max() == 0, (c, int(d.max()))
     kb.delete()
 
 
@@ -583,7 +583,7 @@ def test_dispatch_boundaries(random_model, precision, B, T):
     x = np.tile(base, ((B + 127) // 128, 1))[:B]
     kb = koala_amd.create_batch('key', B, T, precision, model_path=random_model)
     ref = oracle.Oracle(random_model, 128, oracle.PREC_BF16 if precision == 'bf16' else oracle.PREC_FP32)
-    tol = BF16_TOL if precision == 'bf16' else 1
+    tol = BF16_TOL if precision == 'bf16' else FP32_TOL
     for c in range(2):
         y = kb.process(np.ascontiguousarray(x[:, c * T * 256:(c + 1) * T * 256]))
         want = ref.process(np.ascontiguousarray(base[:, c * T * 256:(c + 1) * T * 256]))

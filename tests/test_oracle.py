@@ -164,6 +164,47 @@ def test_stage_entry_points_agree_with_full_path(random_model, test_pcm):
     assert y.dtype == np.int16 and tail.any()
 
 
+def test_spec_transform_agrees_with_textbook_ffts(random_model, test_pcm):
+    """The spec's transform is the packed real FFT-512 the way the GPU evaluates it (FFT-256 = DFT-16 . W_256 . transpose . DFT-16,
+    real-FFT split, inverse by swapping parts: oracle/kns_oracle.c) -- that is what makes the fp32 engine
+    identical to the oracle.  Cross-checks to a tolerance against two independent statements: the oracle's own textbook radix-2
+    FFT over the full 512-point complex block, and numpy's float64 rfft / irfft."""
+    import ctypes as C
+    l = oracle.lib()
+    l.kns_oracle_analysis_radix2.argtypes = [C.c_void_p] * 5
+    l.kns_oracle_synthesis_radix2.argtypes = [C.c_void_p] * 4
+    o = oracle.Oracle(random_model)
+    rng = np.random.default_rng(5)
+    w = np.sin(np.pi * np.arange(512) / 512)
+    for trial in range(6):
+        if trial < 3:
+            hist, pcm = test_pcm[(40 + trial) * 256:(41 + trial) * 256], test_pcm[(41 + trial) * 256:(42 + trial) * 256]
+        else:
+            hist, pcm = (np.clip(rng.standard_normal((2, 256)) * 10 ** (trial - 1), -32768, 32767)).astype(np.int16)
+        spec, feat = o.analysis(hist, pcm)
+        spec2, feat2 = np.empty((257, 2), np.float32), np.empty(257, np.float32)
+        h, p = np.ascontiguousarray(hist), np.ascontiguousarray(pcm)
+        l.kns_oracle_analysis_radix2(o._params, h.ctypes.data, p.ctypes.data, spec2.ctypes.data, feat2.ctypes.data)
+        X = np.fft.rfft(np.concatenate([hist, pcm]).astype(np.float64) / 32768 * w)
+        scale = max(1e-3, float(np.abs(X).max()))
+        assert np.abs(spec[:, 0] + 1j * spec[:, 1] - X).max() < 1e-6 * scale
+        assert np.abs(spec - spec2).max() < 1e-6 * scale
+        big = np.abs(X) > 1e-3 * scale  # (log features of near-empty bins amplify the last bit of the spectrum)
+        assert np.abs(feat - feat2)[big].max() < 1e-3
+        mask = rng.random(257).astype(np.float32)
+        t1 = (rng.standard_normal(256) * 0.01).astype(np.float32)
+        t2, t0 = t1.copy(), t1.astype(np.float64)
+        out1 = oracle.synthesis(spec, mask, t1)
+        out2 = np.empty(256, np.int16)
+        l.kns_oracle_synthesis_radix2(spec.ctypes.data, mask.ctypes.data, t2.ctypes.data, out2.ctypes.data)
+        Y = (spec[:, 0].astype(np.float64) + 1j * spec[:, 1]) * mask
+        Y[0], Y[256] = Y[0].real, Y[256].real
+        y = np.fft.irfft(Y, 512) * w
+        want = np.clip(np.round((t0 + y[:256]) * 32768), -32768, 32767)
+        assert np.abs(out1 - want).max() <= 1 and np.abs(out1.astype(int) - out2).max() <= 1
+        assert np.abs(t1 - y[256:]).max() < 1e-6 * max(1.0, float(np.abs(y).max())) and np.abs(t1 - t2).max() < 1e-6
+
+
 def test_oracle_reproduces_committed_golden_vectors(random_model, prior_gate_model):
     """tests/golden/kns_v1_golden.npz (tools/make_golden.py): the spec pinned as data."""
     g = np.load(os.path.join(GOLDEN, 'kns_v1_golden.npz'))
