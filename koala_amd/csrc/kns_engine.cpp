@@ -51,8 +51,10 @@ LoadResult load_params(const char *path, Params *p, std::string *err) {
         *err = std::string("`") + path + "` is not a Koala (KNS1) model file.";
         return kLoadFormat;
     }
-    p->front_taps = hdr[11] > 1 ? (int) hdr[11] : 1;  // KNS-v1.1: a front-end over the last N feature frames (header word 11)
-    if (p->front_taps > kMaxFrontTaps) {
+    // KNS-v1.1: a front-end over the last N feature frames (header word 11; 0 and 1 both mean one).  Checked as the unsigned
+    // word it is: a value with the top bit set must not become a negative count that passes the test and sizes a vector.
+    p->front_taps = hdr[11] > 1 && hdr[11] <= (uint32_t) kMaxFrontTaps ? (int) hdr[11] : 1;
+    if (hdr[11] > (uint32_t) kMaxFrontTaps) {
         fclose(f);
         *err = std::string("`") + path + "` has a front-end over " + std::to_string(hdr[11]) + " feature frames (at most " +
                std::to_string(kMaxFrontTaps) + " are supported).";
@@ -88,39 +90,6 @@ LoadResult load_params(const char *path, Params *p, std::string *err) {
 // ------------------------------------------------------------------------------------------------ weight packing
 
 namespace {
-
-// the spec's logarithm (the device's kns_log in kns_device.hpp, operation for operation): the host needs
-// one value of it, the feature of a silent frame that a five-frame front-end sees before a stream began
-float host_kns_log(float x) {
-    uint32_t u;
-    memcpy(&u, &x, 4);
-    int e = (int) ((u >> 23) & 0xffu) - 126;
-    uint32_t mu = (u & 0x007fffffu) | 0x3f000000u;
-    float m;
-    memcpy(&m, &mu, 4);
-    if (m < 0.707106781186547524f) {
-        e -= 1;
-        m = (m + m) - 1.0f;
-    } else {
-        m = m - 1.0f;
-    }
-    float z = m * m;
-    float p = 7.0376836292e-2f;
-    p = fmaf(p, m, -1.1514610310e-1f);
-    p = fmaf(p, m, 1.1676998740e-1f);
-    p = fmaf(p, m, -1.2420140846e-1f);
-    p = fmaf(p, m, 1.4249322787e-1f);
-    p = fmaf(p, m, -1.6668057665e-1f);
-    p = fmaf(p, m, 2.0000714765e-1f);
-    p = fmaf(p, m, -2.4999993993e-1f);
-    p = fmaf(p, m, 3.3333331174e-1f);
-    float fe = (float) e;
-    float y = (p * m) * z;
-    y = fmaf(fe, -2.12194440e-4f, y);
-    y = fmaf(z, -0.5f, y);
-    float r = m + y;
-    return fmaf(fe, 0.693359375f, r);
-}
 
 struct Seg {
     int k0, klen;
@@ -414,22 +383,10 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
         // taps_ slots: slots 1 .. taps_ - 1 hold the features of the last taps_ - 1 frames; slot 0 is where a one-frame call's roll
         // puts the oldest tap (kns_stft.hip, AnalysisArgs::feat_hist)
         d_fhist_ = dalloc((size_t) taps_ * feat_frame_bytes_, true);
-        // one m-tile whose 16 rows are the feature of a silent frame, in the operand type and layout of `feat`
-        std::vector<uint8_t> tile((size_t) nbf_ * 1024, 0);
-        const float lg = host_kns_log(1e-10f);
-        for (int k = 0; k < kBins; ++k) {
-            const float v = (lg - p.mean[k]) * p.scale[k];
-            for (int r = 0; r < 16; ++r) {
-                const size_t off = (size_t) (k / pi_.kb) * 1024 + (size_t) pack_off(precision, r, k % pi_.kb) * pi_.esz;
-                if (precision == kBf16) {
-                    const uint16_t h = to_bf16(v);
-                    memcpy(tile.data() + off, &h, 2);
-                } else {
-                    memcpy(tile.data() + off, &v, 4);
-                }
-            }
-        }
-        d_silent_ = upload(tile.data(), tile.size());
+        // one m-tile whose 16 rows are the feature of a silent frame, in the operand type and layout of `feat`: made by the
+        // analysis kernel itself from 16 streams of zeros, so that "reset" and "silent frames" are the same bits in both
+        // configurations (the bf16 one takes its logarithm from v_log_f32, which no host formula reproduces)
+        d_silent_ = dalloc((size_t) nbf_ * 1024, true);
     }
     d_e_ = dalloc(M * nbh_ * 1024, true);
     for (int s = 0; s < kStages - 1; ++s) d_y_[s] = dalloc(M * nby_[s] * 1024, true);
@@ -438,7 +395,8 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     d_hseq_b_ = dalloc(M * nbh_ * 1024, true);
     d_mask_ = (float *) dalloc(M * kMaskTiles * 1024, true);
     if (use_quad_ && gru_quad_supported(prec_, (int) mtb, 0)) {
-        d_xchg_ = dalloc(mtb * kQuadXchgBytesPerMtile, true);  // tags start at 0 = never valid
+        // the granule exchange buffer belongs to the multi-frame form, which only the developer build's KOALA_AMD_QUAD arm runs
+        if (quad_all_) d_xchg_ = dalloc(mtb * kQuadXchgBytesPerMtile, true);  // tags start at 0 = never valid
         d_qerr_ = (unsigned *) dalloc(16, true);
     } else {
         use_quad_ = false;
@@ -459,6 +417,24 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
         return false;
     }
     if (taps_ > 1) {  // the front-end context of a fresh stream is silence, not zeros
+        AnalysisArgs an;
+        an.pcm = d_in_;  // zeros (at least one frame of B_ >= 1 streams; rows past the last stream re-read the last one)
+        an.hist_in = d_hist_[0];
+        an.hist_out = d_hist_[0];  // (zeros over zeros)
+        an.window = d_window_;
+        an.twiddle = d_twiddle_;
+        an.mean = d_mean_;
+        an.scale = d_scale_;
+        an.spec = nullptr;
+        an.feat = d_silent_;
+        an.B = 1;
+        an.Bpad = 16;
+        an.T = 1;
+        an.nbf = nbf_;
+        an.precision = prec_;
+        an.seg = 1;
+        an.write_spec = 0;
+        launch_analysis(an, own_stream_);
         std::string e2;
         if (!reset(nullptr, &e2)) {
             *err = e2;
@@ -675,6 +651,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         an.front_valid = kHidden;
         an.feat = nullptr;
     }
+    feat_valid_ = !front_in_analysis && !roll_in_analysis;  // (otherwise the feature tile never left the CU / went to the history slots)
     const int16_t *hist_before = d_hist_[hist_cur_];
     const int only = dev_only_class_;  // -1 in the product library
     tick(kClsAnalysis);
@@ -799,7 +776,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         g.serial = quad_serial_;
         g.dbg = d_qdbg_;
         g.dbg_block = qdbg_block_;
-        quad_used_ = true;
+        if (T > 1) quad_used_ = true;  // (the one-step form has no exchange, no bounded wait and writes no error word)
         tick(kClsGru);
         if (only < 0 || only == kClsGru) launch_gru_quad(g, stream_);
         tock(kClsGru);
@@ -817,6 +794,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     // ... and the mask head in the synthesis launch (bf16, stored spectrum -- what a one-frame call uses; kns_stft.hip, kMaskIn)
     const bool mask_in_synthesis = T == 1 && prec_ == kBf16 && fuse_front_ && !debug_taps_ && !recompute &&
                                    sd_[kStages - 1].head_tiles == kMaskTiles;
+    mask_valid_ = !mask_in_synthesis;
     bool head_in_next = false;  // stage s - 1's head has been left to this stage's first layer
     for (int s = 0; s < kStages; ++s) {
         const StageDev &d = sd_[s];
@@ -1021,7 +999,9 @@ bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err, 
     }
     if (T > host_chunk_ && bytes >= host_pipeline_min_bytes_) {
         const char *pa = (const char *) pcm, *pb = (const char *) out;
-        if (pa < pb + bytes && pb < pa + bytes) {  // chunk c's copy-out would land on input chunks not yet read
+        // partial overlap: chunk c's copy-out would land on input chunks not yet read.  EXACT aliasing (enhanced == pcm) is fine:
+        // chunk c's output columns are chunk c's own input columns, which have been staged by then
+        if (pa != pb && pa < pb + bytes && pb < pa + bytes) {
             *err = "`pcm` and `enhanced` overlap: host-memory calls of this size are pipelined in sub-chunks and need "
                    "disjoint buffers.";
             return false;
@@ -1135,6 +1115,11 @@ int64_t Engine::debug_read(int what, float *out, int64_t capacity, std::string *
         return v;
     };
     int64_t n = 0;
+    if ((what == 0 && !feat_valid_) || (what == 2 && !mask_valid_)) {
+        *err = "the last call kept this intermediate on chip (one-frame calls fuse the front-end / the mask head into the STFT "
+               "launches): use the developer build with its debug-taps switch";
+        return -1;
+    }
     if (what == 0 || what == 4) {  // features / embedding
         const int width = what == 0 ? kBins : kHidden, nb = what == 0 ? nbf_ : nbh_;
         n = (int64_t) T * B_ * width;

@@ -118,7 +118,8 @@ private:
     bool check_quad_error(std::string *err);
     unsigned long long *d_qdbg_ = nullptr;  // developer build, KOALA_AMD_QUAD_DBG=<block>: stamps of the LAST fused launch
     int qdbg_block_ = -1;
-    bool spec_valid_ = false;  // the last run_device() stored the spectrum (debug_read(1) refuses otherwise)
+    // the last run_device() stored the spectrum / the features / the mask (debug_read refuses a tap that was not stored)
+    bool spec_valid_ = false, feat_valid_ = false, mask_valid_ = false;
 
     // profiling
     bool profiling_ = false;

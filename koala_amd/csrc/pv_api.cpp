@@ -12,6 +12,8 @@
 #include <string.h>
 
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -99,9 +101,30 @@ bool parse_device(const char *text, DeviceSpec *out) {
     return false;
 }
 
+// No C++ exception may cross the C ABI (the callers are ctypes / dlsym hosts: an escaping exception is std::terminate).  Every
+// entry point that reaches engine code runs it through this: bad_alloc -> OUT_OF_MEMORY, anything else -> RUNTIME_ERROR.
+template <class F>
+pv_status_t guarded(F &&body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        push_error(0x65, "Failed to allocate memory.");
+        return PV_STATUS_OUT_OF_MEMORY;
+    } catch (const std::length_error &) {
+        push_error(0x65, "Failed to allocate memory.");
+        return PV_STATUS_OUT_OF_MEMORY;
+    } catch (const std::exception &e) {
+        push_error(0x339, "Unexpected failure: %s", e.what());
+        return PV_STATUS_RUNTIME_ERROR;
+    } catch (...) {
+        push_error(0x339, "Unexpected failure.");
+        return PV_STATUS_RUNTIME_ERROR;
+    }
+}
+
 // shared front half of pv_koala_init / pv_koala_batch_init
-pv_status_t open_engine(const char *access_key, const char *model_path, const char *device, void *object,
-                        int num_streams, int max_frames, int precision, kns::Engine **engine) {
+pv_status_t open_engine_unguarded(const char *access_key, const char *model_path, const char *device, void *object,
+                                  int num_streams, int max_frames, int precision, kns::Engine **engine) {
     if (!access_key) {
         push_error(0x64, "Argument `access_key` is NULL.");
         return PV_STATUS_INVALID_ARGUMENT;
@@ -169,6 +192,11 @@ pv_status_t open_engine(const char *access_key, const char *model_path, const ch
     }
     *engine = e;
     return PV_STATUS_SUCCESS;
+}
+
+pv_status_t open_engine(const char *access_key, const char *model_path, const char *device, void *object, int num_streams,
+                        int max_frames, int precision, kns::Engine **engine) {
+    return guarded([&] { return open_engine_unguarded(access_key, model_path, device, object, num_streams, max_frames, precision, engine); });
 }
 
 int default_precision() {
@@ -270,24 +298,28 @@ PV_API pv_status_t pv_koala_process(pv_koala_t *object, const int16_t *pcm, int1
         push_error(0x64, "Argument `enhanced_pcm` is NULL.");
         return PV_STATUS_INVALID_ARGUMENT;
     }
-    std::string err;
-    if (!object->engine->process(1, pcm, enhanced_pcm, &err, /*host_pointers=*/true)) {
-        push_error(0x337, "%s", err.c_str());
-        push_error(0x12C, "Picovoice Error.");
-        return PV_STATUS_RUNTIME_ERROR;
-    }
-    return PV_STATUS_SUCCESS;
+    return guarded([&] {
+        std::string err;
+        if (!object->engine->process(1, pcm, enhanced_pcm, &err, /*host_pointers=*/true)) {
+            push_error(0x337, "%s", err.c_str());
+            push_error(0x12C, "Picovoice Error.");
+            return PV_STATUS_RUNTIME_ERROR;
+        }
+        return PV_STATUS_SUCCESS;
+    });
 }
 
 PV_API pv_status_t pv_koala_reset(pv_koala_t *object) {
     t_stack.clear();
     if (!object) return PV_STATUS_INVALID_ARGUMENT;  // the reference leaves no message for this one
-    std::string err;
-    if (!object->engine->reset(nullptr, &err)) {
-        push_error(0x338, "%s", err.c_str());
-        return PV_STATUS_RUNTIME_ERROR;
-    }
-    return PV_STATUS_SUCCESS;
+    return guarded([&] {
+        std::string err;
+        if (!object->engine->reset(nullptr, &err)) {
+            push_error(0x338, "%s", err.c_str());
+            return PV_STATUS_RUNTIME_ERROR;
+        }
+        return PV_STATUS_SUCCESS;
+    });
 }
 
 PV_API pv_status_t pv_koala_delay_sample(const pv_koala_t *object, int32_t *delay_sample) {
@@ -379,13 +411,15 @@ PV_API pv_status_t pv_koala_batch_process_chunk(pv_koala_batch_t *object, int32_
         push_error(0x66, "`num_frames` %d is outside [1, %d].", num_frames, object->engine->max_frames());
         return PV_STATUS_INVALID_ARGUMENT;
     }
-    std::string err;
-    if (!object->engine->process(num_frames, pcm, enhanced, &err)) {
-        push_error(0x337, "%s", err.c_str());
-        push_error(0x12C, "Picovoice Error.");
-        return PV_STATUS_RUNTIME_ERROR;
-    }
-    return PV_STATUS_SUCCESS;
+    return guarded([&] {
+        std::string err;
+        if (!object->engine->process(num_frames, pcm, enhanced, &err)) {
+            push_error(0x337, "%s", err.c_str());
+            push_error(0x12C, "Picovoice Error.");
+            return PV_STATUS_RUNTIME_ERROR;
+        }
+        return PV_STATUS_SUCCESS;
+    });
 }
 
 PV_API pv_status_t pv_koala_batch_process(pv_koala_batch_t *object, const int16_t *pcm, int16_t *enhanced) {
@@ -398,12 +432,14 @@ PV_API pv_status_t pv_koala_batch_reset(pv_koala_batch_t *object, const uint8_t 
         push_error(0x64, "Argument `object` is NULL.");
         return PV_STATUS_INVALID_ARGUMENT;
     }
-    std::string err;
-    if (!object->engine->reset(stream_mask, &err)) {
-        push_error(0x338, "%s", err.c_str());
-        return PV_STATUS_RUNTIME_ERROR;
-    }
-    return PV_STATUS_SUCCESS;
+    return guarded([&] {
+        std::string err;
+        if (!object->engine->reset(stream_mask, &err)) {
+            push_error(0x338, "%s", err.c_str());
+            return PV_STATUS_RUNTIME_ERROR;
+        }
+        return PV_STATUS_SUCCESS;
+    });
 }
 
 PV_API pv_status_t pv_koala_batch_num_streams(const pv_koala_batch_t *object, int32_t *num_streams) {
@@ -506,7 +542,12 @@ PV_API int64_t pv_koala_batch_debug_read(pv_koala_batch_t *object, int32_t what,
     t_stack.clear();
     if (!object || !out) return -(int64_t) PV_STATUS_INVALID_ARGUMENT;
     std::string err;
-    int64_t n = object->engine->debug_read(what, out, capacity, &err);
+    int64_t n = -1;
+    try {
+        n = object->engine->debug_read(what, out, capacity, &err);
+    } catch (...) {
+        err = "Failed to allocate memory.";
+    }
     if (n < 0) {
         push_error(0x33A, "%s", n == -2 ? "capacity too small" : err.c_str());
         return -(int64_t) PV_STATUS_INVALID_ARGUMENT;

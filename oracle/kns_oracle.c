@@ -183,8 +183,8 @@ int kns_params_load(const char *path, int precision, kns_params_t **out) {
     kns_params_t *p = (kns_params_t *) calloc(1, sizeof(*p));
     p->precision = precision;
     p->delay = (int) hdr[10];
-    p->front_taps = hdr[11] > 1 ? (int) hdr[11] : 1;
-    if (p->front_taps > KNS_MAX_FRONT_TAPS) {
+    p->front_taps = hdr[11] > 1 && hdr[11] <= (uint32_t) KNS_MAX_FRONT_TAPS ? (int) hdr[11] : 1;
+    if (hdr[11] > (uint32_t) KNS_MAX_FRONT_TAPS) { /* (compared as the unsigned word it is) */
         fclose(f);
         free(p);
         return -2;
