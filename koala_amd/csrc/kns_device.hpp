@@ -309,8 +309,6 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.88539008177792681f));
 }
 
-constexpr int kResBiasBytes = kGateTiles * 16 * 4;
-
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
@@ -375,8 +373,9 @@ __device__ __forceinline__ float mix_fma(float a, float b, unsigned x) {
 }
 
 // ---- the bf16 configuration's gate arithmetic, shared by every bf16 recurrent kernel.  The operands arrive PRE-SCALED (the
-// constants of the exponentials are folded into the packed weights and biases, kns_layout.h) and the recurrent accumulators
-// start from b_hh, so a hidden unit costs 9 plain vector operations and 6 transcendentals:
+// constants of the exponentials are folded into the packed weights and biases, kns_layout.h) and b_hh is part of the recurrent
+// GEMM itself (two rows of the packed W_hh against a constant 1 in the operand, kBiasK0), so a hidden unit costs 9 plain vector
+// operations and 6 transcendentals and a step fetches no bias:
 //   r = 1 / (1 + 2^(gi_r + gh_r))   z = 1 / (1 + 2^(gi_z + gh_z))   n = 1 - 2 / (1 + 2^(fma(r, gh_n, gi_n)))   h' = fma(z, h - n, n)
 __device__ __forceinline__ float gate_rcp1p_exp2(float y) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y)); }
 // gi as packed fp16 pairs (element 2 p and 2 p + 1 of the C fragment in word p), gh as fp32 C fragments, h the previous state

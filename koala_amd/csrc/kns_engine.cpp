@@ -264,13 +264,10 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     dev_synth_seg_ = dev_int("KOALA_AMD_SYNTH_SEG", 0);
     dev_small_mt_ = dev_int("KOALA_AMD_SMALL_MT", 0);
     dev_steps_mt_ = dev_int("KOALA_AMD_STEPS_MT", 192);
-    // GRU layers as ONE launch fused over CU quads (kns_gruq.hip), bit-identical to the two-kernel form.  Taken for ONE-FRAME
-    // calls of large batches (its one-step form, gru_quad1_kernel), where a CU then pulls a quarter of W_ih and W_hh (300 KiB)
-    // per layer instead of a half of one and all of the other (~740 KiB) and a layer is one launch: 128 against 222 us per
-    // 4096-stream frame step; a one-step launch has no exchange between workgroups at all.  For multi-frame calls it measured slower (354 against 278 us per layer at
-    // 64 frames): there it is an A/B arm of the developer build (KOALA_AMD_QUAD=1; KOALA_AMD_NO_QUAD=1
-    // turns it off everywhere).
-    quad_all_ = dev_env("KOALA_AMD_QUAD") != nullptr;
+    // One-frame calls of large batches: a GRU layer as ONE launch fused over CU quads (kns_gruq.hip, gru_quad1_kernel), bit-identical
+    // to the two-kernel form -- a CU pulls a quarter of W_ih and W_hh (300 KiB) per layer instead of a half of one and all of the
+    // other (~740 KiB): 128 against 222 us per 4096-stream frame step.  (The multi-frame form of that decomposition measured slower
+    // than input GEMM + recurrent kernel, 354 against 278 us per layer at 64 frames, and is no longer in the tree: DESIGN.md section 6.)
     use_quad_ = dev_env("KOALA_AMD_NO_QUAD") == nullptr;
     fuse_head_ = dev_env("KOALA_AMD_NO_HEAD_FUSE") == nullptr;
     fuse_front_ = dev_env("KOALA_AMD_NO_STFT_FUSE") == nullptr;  // A/B arm: front-end / mask head as launches of their own in one-frame calls  // A/B arm: narrow heads as launches of their own in one-frame calls
@@ -346,10 +343,28 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
             auto img = pack_bias(gate_scaled(b, 1).data(), gt);
             return (float *) upload(img.data(), img.size() * 4);
         };
+        // bf16 configuration: b_hh becomes rows kBiasK0, kBiasK0 + 1 of the packed W_hh -- the scaled bias as a bf16 pair, hi =
+        // bf16(b), lo = bf16(b - hi) -- multiplied by the constant 1 every bf16 recurrent kernel keeps at those k of the hidden-state
+        // operand (kns_layout.h; the oracle's bf16 mode appends the same two rows)
+        auto pk_hh = [&](const std::vector<float> &w, const std::vector<float> &b) {
+            if (precision != kBf16) return pk(w, {{0, kHidden}});
+            std::vector<float> aug = gate_scaled(w, kHidden), bs = gate_scaled(b, 1);
+            aug.resize((size_t) (kHidden + 2) * G3);
+            for (int c = 0; c < G3; ++c) {
+                const uint16_t hb = to_bf16(bs[c]);
+                const uint32_t hu = (uint32_t) hb << 16;
+                float hi;
+                memcpy(&hi, &hu, 4);
+                aug[(size_t) kBiasK0 * G3 + c] = hi;
+                aug[(size_t) (kBiasK0 + 1) * G3 + c] = bs[c] - hi;  // (exact in fp32; rounded to bf16 by pack_b)
+            }
+            auto img = pack_b(aug.data(), G3, {{0, kHidden + 2}}, gt, precision);
+            return upload(img.data(), img.size());
+        };
         d.w_ih_a = pk(st.w_ih_a, segs_a);
-        d.w_hh_a = pk(st.w_hh_a, {{0, kHidden}});
+        d.w_hh_a = pk_hh(st.w_hh_a, st.b_hh_a);
         d.w_ih_b = pk(st.w_ih_b, {{0, kHidden}});
-        d.w_hh_b = pk(st.w_hh_b, {{0, kHidden}});
+        d.w_hh_b = pk_hh(st.w_hh_b, st.b_hh_b);
         d.b_ih_a = pb(st.b_ih_a);
         d.b_hh_a = pb(st.b_hh_a);
         d.b_ih_b = pb(st.b_ih_b);
@@ -394,14 +409,8 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     d_hseq_a_ = dalloc(M * nbh_ * 1024, true);
     d_hseq_b_ = dalloc(M * nbh_ * 1024, true);
     d_mask_ = (float *) dalloc(M * kMaskTiles * 1024, true);
-    if (use_quad_ && gru_quad_supported(prec_, (int) mtb, 0)) {
-        // the granule exchange buffer belongs to the multi-frame form, which only the developer build's KOALA_AMD_QUAD arm runs
-        if (quad_all_) d_xchg_ = dalloc(mtb * kQuadXchgBytesPerMtile, true);  // tags start at 0 = never valid
-        d_qerr_ = (unsigned *) dalloc(16, true);
-    } else {
-        use_quad_ = false;
-    }
-    if (qdbg_block_ >= 0) d_qdbg_ = (unsigned long long *) dalloc((size_t) 8 * 4 * Tmax_ * 8 * 8, true);
+    if (!gru_quad_supported(prec_, (int) mtb, 0)) use_quad_ = false;
+    if (qdbg_block_ >= 0) d_qdbg_ = (unsigned long long *) dalloc((size_t) 8 * 4 * 8 * 8, true);
     d_in_ = (int16_t *) dalloc((size_t) B_ * Tmax_ * kFrame * 2, true);
     d_out_ = (int16_t *) dalloc((size_t) B_ * Tmax_ * kFrame * 2, true);
     if (alloc_failed_) {
@@ -530,27 +539,6 @@ bool Engine::profile_read(double *ms, int64_t *launches, std::string *err) {
 bool Engine::synchronize(std::string *err) {
     if (hipStreamSynchronize(stream_) != hipSuccess) {
         *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
-        return false;
-    }
-    return check_quad_error(err);
-}
-
-// The fused layer kernel's waits are bounded: a workgroup that runs out of patience records a code and leaves, and the
-// results of that call are garbage.  The word is read back wherever the host waits for the stream anyway.
-bool Engine::check_quad_error(std::string *err) {
-    if (!quad_used_) return true;
-    quad_used_ = false;
-    unsigned code[4] = {0, 0, 0, 0};
-    if (hipMemcpyAsync(code, d_qerr_, sizeof(code), hipMemcpyDeviceToHost, stream_) != hipSuccess ||
-        hipStreamSynchronize(stream_) != hipSuccess) {
-        *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
-        return false;
-    }
-    if (code[0] != 0) {
-        char msg[160];
-        snprintf(msg, sizeof(msg), "fused GRU layer kernel gave up waiting (code 0x%08x): results of the call are invalid", code[0]);
-        *err = msg;
-        (void) hipMemsetAsync(d_qerr_, 0, 16, stream_);
         return false;
     }
     return true;
@@ -745,10 +733,10 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         tock(kClsGru);
     };
 
-    // Chunked bf16 calls whose m-tiles come in whole quads: a GRU layer is ONE launch (kns_gruq.hip) -- input GEMM, recurrent
-    // GEMM and gates fused over CU quads, no pre-activation round trip through HBM.  Same arithmetic as the two-kernel form,
-    // bit for bit (tests/test_gpu_parity.py::test_alternative_kernels_give_identical_pcm).
-    const bool quad = use_quad_ && !small && !small_steps && (T == 1 || (quad_all_ && T < 4096));
+    // One-frame bf16 calls whose m-tiles come in whole quads (from 60 m-tiles on): a GRU layer is ONE launch (kns_gruq.hip) -- input
+    // GEMM, recurrent GEMM and gates fused over CU quads.  Same arithmetic as the two-kernel form, bit for bit
+    // (tests/test_gpu_parity.py::test_alternative_kernels_give_identical_pcm).
+    const bool quad = use_quad_ && !small && T == 1;
     auto gru_quad = [&](const void *a0, int nb0, const void *a1, const void *wih, const float *bih, const void *whh,
                         const float *bhh, int layer, void *hseq, const StageDev *head = nullptr) {
         GruQuadArgs g;
@@ -767,16 +755,10 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         g.hstate_in = d_hstate_[hs_cur_] + (size_t) layer * mtb * kUnitTiles * 256;
         g.hstate_out = d_hstate_[hs_cur_ ^ 1] + (size_t) layer * mtb * kUnitTiles * 256;
         g.hseq = hseq;
-        g.xchg = d_xchg_;
-        g.err = d_qerr_;
         g.nb0 = nb0;
-        g.T = T;
         g.mtiles = mtb;
-        quad_serial_ = quad_serial_ >= (1u << 20) - 1 ? 1 : quad_serial_ + 1;
-        g.serial = quad_serial_;
         g.dbg = d_qdbg_;
         g.dbg_block = qdbg_block_;
-        if (T > 1) quad_used_ = true;  // (the one-step form has no exchange, no bounded wait and writes no error word)
         tick(kClsGru);
         if (only < 0 || only == kClsGru) launch_gru_quad(g, stream_);
         tock(kClsGru);
@@ -980,7 +962,7 @@ bool Engine::process_host_pipelined(int T, const int16_t *pcm, int16_t *out, boo
         (void) hipDeviceSynchronize();
         return false;
     }
-    return check_quad_error(err);
+    return true;
 }
 
 bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err, bool host_pointers) {
@@ -1054,7 +1036,6 @@ bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err, 
     if (!run_device(T, d_in_, d_out_, err)) return false;
     if (hipMemcpyAsync(h_out_, d_out_, bytes, hipMemcpyDeviceToHost, stream_) != hipSuccess) goto fail;
     if (hipStreamSynchronize(stream_) != hipSuccess) goto fail;
-    if (!check_quad_error(err)) return false;
     memcpy(out, h_out_, bytes);
     return true;
 fail:

@@ -108,14 +108,10 @@ private:
     bool use_graph_ = true, no_small_ = false, no_zero_copy_ = false, no_recompute_ = false, debug_taps_ = false;
     // developer switches (all read once in init() through dev_env(): compiled out of the product library)
     int dev_variant_ = 0, dev_only_class_ = -1, dev_analysis_seg_ = 0, dev_synth_seg_ = 0, dev_small_mt_ = 0, dev_steps_mt_ = 192;
-    // fused GRU layers over CU quads (kns_gruq.hip): granule exchange buffer, device error words, launch serial (tag bits)
-    void *d_xchg_ = nullptr;
-    unsigned *d_qerr_ = nullptr;
-    unsigned quad_serial_ = 0;
-    bool use_quad_ = true, quad_all_ = false, quad_used_ = false;
+    // one-frame calls: GRU layers fused over CU quads (kns_gruq.hip); narrow heads / front-end / mask head inside their consumers
+    bool use_quad_ = true;
     int quad_nb0_max_ = 2;
     bool fuse_head_ = true, fuse_front_ = true;
-    bool check_quad_error(std::string *err);
     unsigned long long *d_qdbg_ = nullptr;  // developer build, KOALA_AMD_QUAD_DBG=<block>: stamps of the LAST fused launch
     int qdbg_block_ = -1;
     // the last run_device() stored the spectrum / the features / the mask (debug_read refuses a tap that was not stored)

@@ -30,6 +30,16 @@ __global__ __launch_bounds__(64 * W, W / 4) void gru_kernel(GruArgs g) {
     }
     for (int i = tid; i < 2 * NBH * 64; i += 64 * W) ((uint4 *) hbuf)[i] = uint4{0, 0, 0, 0};
     __syncthreads();
+    // bf16 configuration: the operand's k = 271, 272 are the constant 1 against the two bias rows of the packed W_hh (kns_layout.h,
+    // kBiasK0); k = 271 is rewritten with every image of tile 16 (operand_of below), k = 272 stays as set here, in both buffers
+    if (P::kPrec == kBf16 && tid < 64) {
+        const int k = kBiasK0 + ((tid >> 4) & 1);
+        ((elem_t *) hbuf[tid >> 5])[(k / P::KB) * 64 * P::EPL + P::off(tid & 15, k % P::KB)] = (elem_t) kBf16One;
+    }
+    auto operand_of = [&](float h, int u) -> elem_t {
+        if (P::kPrec == kBf16 && u == kUnitTiles - 1 && colq == 15) return (elem_t) kBf16One;
+        return P::cvt(h);
+    };
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
         const int u = wave + W * q;
@@ -37,7 +47,7 @@ __global__ __launch_bounds__(64 * W, W / 4) void gru_kernel(GruArgs g) {
             const int k = u * 16 + colq;
             elem_t *dst = (elem_t *) hbuf[0] + (k / P::KB) * 64 * P::EPL;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dst[P::off(rowq + i, k % P::KB)] = P::cvt(hreg[q][i]);
+            for (int i = 0; i < 4; ++i) dst[P::off(rowq + i, k % P::KB)] = operand_of(hreg[q][i], u);
         }
     }
     __syncthreads();
@@ -63,12 +73,7 @@ __global__ __launch_bounds__(64 * W, W / 4) void gru_kernel(GruArgs g) {
                 const float bn = g.bhh[(u * 3 + 2) * 16 + colq];
                 f32x4 acc[3];
 #pragma unroll
-                for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (P::kPrec == kBf16) {  // bf16 configuration: the recurrent chains start from b_hh (kns_device.hpp, gate_block_bf16)
-                    acc[0] = f32x4{br, br, br, br};
-                    acc[1] = f32x4{bz, bz, bz, bz};
-                    acc[2] = f32x4{bn, bn, bn, bn};
-                }
+                for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};  // (bf16: b_hh rides in the operands, kns_layout.h)
                 // B fragments two k-blocks ahead of their MFMAs, rotated through registers (a rolled loop: unrolling all 51
                 // fp32 k-block/gate pairs makes hipcc materialise an address pair per load and spill)
                 const frag_t *wu = whh + (size_t) u * 3 * NBH * 64 + lane;
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(64 * W, W / 4) void gru_kernel(GruArgs g) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) hreg[q][i] = gate_elem_bf16(ir[i], iz[i], in[i], acc[0][i], acc[1][i], acc[2][i], hreg[q][i]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) dst[P::off(rowq + i, k % P::KB)] = P::cvt(hreg[q][i]);
+                    for (int i = 0; i < 4; ++i) dst[P::off(rowq + i, k % P::KB)] = operand_of(hreg[q][i], u);
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -192,7 +197,6 @@ __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
 #pragma unroll
     for (int p = 0; p < NBH; ++p) wh[p] = whh[(size_t) p * 64];
     const float bi = g.bih[(u * 3 + gt) * 16 + colq];
-    const float bh = g.bhh[(u * 3 + gt) * 16 + colq];
     const float br = g.bhh[(u * 3 + 0) * 16 + colq], bz = g.bhh[(u * 3 + 1) * 16 + colq], bn = g.bhh[(u * 3 + 2) * 16 + colq];
     __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks the loads to their uses to save registers: five round trips again)
 
@@ -205,7 +209,13 @@ __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
         elem_t *dst = v * 16 < NBH * P::KB ? (elem_t *) hbuf + (k / P::KB) * 64 * P::EPL : (elem_t *) hspare;
         const uint32_t keep = v < kUnitTiles ? 0xffffffffu : 0u;  // (a mask, not a branch: slot 17 is the zero tile)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dst[P::off(rowq + i, k % P::KB)] = P::cvt(u2f(f2u(hv[q][i]) & keep));
+        for (int i = 0; i < 4; ++i) {
+            elem_t e = P::cvt(u2f(f2u(hv[q][i]) & keep));
+            // bf16 configuration: k = 271 (column 15 of tile 16) and k = 272 (column 0 of the empty slot 17) are the constant 1
+            // against the two bias rows of the packed W_hh (kns_layout.h, kBiasK0)
+            if (P::kPrec == kBf16 && ((v == kUnitTiles - 1 && colq == 15) || (v == kUnitTiles && colq == 0))) e = (elem_t) kBf16One;
+            dst[P::off(rowq + i, k % P::KB)] = e;
+        }
     }
     static_assert(3 * kHT * 16 >= NBH * P::KB, "the three waves' tile slots cover the operand image");
 
@@ -226,7 +236,6 @@ __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
         }
     }
     f32x4 acci = f32x4{0.f, 0.f, 0.f, 0.f}, acch = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (P::kPrec == kBf16) acch = f32x4{bh, bh, bh, bh};  // bf16 configuration: this gate's recurrent chain starts from its b_hh
     if (!kHead) {
 #pragma unroll
         for (int p = 0; p < nb; ++p) acci = P::mma(xa[p], wi[p], acci);
@@ -304,7 +313,7 @@ constexpr int kR8Waves = 8;
 #endif
 constexpr int kR8RegFrags1 = 14;                      // fragments of the second tile kept in registers
 constexpr int kR8LdsFrags1 = 27 - kR8RegFrags1;       // ... and in LDS
-constexpr int kR8Lds = 2 * PBF16::NBH * 1024 + kR8Waves * kR8LdsFrags1 * 1024 + 27 * 1024 + kResBiasBytes;
+constexpr int kR8Lds = 2 * PBF16::NBH * 1024 + kR8Waves * kR8LdsFrags1 * 1024 + 27 * 1024;
 
 // MFMAs of one unit tile whose fragments [first_lds, 27) live in LDS at wl[(i - first_lds)] (i = k_block * 3 + gate) and
 // the rest in wreg[i]; LDS fragments go through a kQ-deep register queue
@@ -350,7 +359,6 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     char *hbuf0 = smem, *hbuf1 = smem + NBH * 1024;
     frag_t *wl1 = (frag_t *) (smem + 2 * NBH * 1024);                                   // [8 waves][13][64]
     frag_t *wl16 = (frag_t *) (smem + 2 * NBH * 1024 + kR8Waves * kR8LdsFrags1 * 1024);  // [27][64], i = blk * 3 + gate
-    float *lbias = (float *) (smem + 2 * NBH * 1024 + kR8Waves * kR8LdsFrags1 * 1024 + 27 * 1024);
     f32x4 *acc16 = (f32x4 *) (smem + kR8Lds);  // [3 gates][64 lanes]: unit tile 16's accumulators, handed across waves
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -390,13 +398,6 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     for (int i = 0; i < 27; ++i) w0[i] = whh[((size_t) (u0 * 3 + i % 3) * NBH + i / 3) * 64 + lane];
 #pragma unroll
     for (int i = 0; i < kR8RegFrags1; ++i) w1[i] = whh[((size_t) (u1 * 3 + i % 3) * NBH + i / 3) * 64 + lane];
-    constexpr int kBiasPer = (kGateTiles * 16 + 64 * kR8Waves - 1) / (64 * kR8Waves);
-    float bias_in[kBiasPer];
-#pragma unroll
-    for (int q = 0; q < kBiasPer; ++q) {
-        const int i = tid + 64 * kR8Waves * q;
-        bias_in[q] = g.bhh[i < kGateTiles * 16 ? i : kGateTiles * 16 - 1];
-    }
     f32x4 hreg[2];
     hreg[0] = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u0) * 64 + lane];
     hreg[1] = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u1) * 64 + lane];
@@ -414,12 +415,14 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     }
     for (int i = tid; i < 2 * NBH * 64; i += 64 * kR8Waves) ((uint4 *) smem)[i] = uint4{0, 0, 0, 0};
     if (tid < 4) ((int *) (smem + kR8Lds + 3 * 1024))[tid] = 0;
-#pragma unroll
-    for (int q = 0; q < kBiasPer; ++q) {
-        const int i = tid + 64 * kR8Waves * q;
-        if (i < kGateTiles * 16) lbias[i] = bias_in[q];
-    }
     __syncthreads();
+    // the operand's k = 271, 272 are the constant 1 against the two bias rows of the packed W_hh (kns_layout.h, kBiasK0): no bias
+    // fetch and no accumulator splat in the step.  k = 271 (column 15 of tile 16) is rewritten by put_h16 every step, k = 272 is
+    // past every tile and stays as set here, in both buffers.
+    if (tid < 64) {
+        const int k = kBiasK0 + ((tid >> 4) & 1);
+        ((uint16_t *) ((tid >> 5) ? hbuf1 : hbuf0))[(k / P::KB) * 64 * P::EPL + P::off(tid & 15, k % P::KB)] = (uint16_t) kBf16One;
+    }
     auto put_h = [&](char *buf, int u, const f32x4 &h) {
         const int k = u * 16 + colq;
         uint16_t *dst = (uint16_t *) buf + (k / P::KB) * 64 * P::EPL + P::off(rowq, k % P::KB);
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     auto put_h16 = [&](char *buf, float h) {  // one row of tile 16
         const int k = u2 * 16 + colq;
         uint16_t *dst = (uint16_t *) buf + (k / P::KB) * 64 * P::EPL + P::off(rowq + e16, k % P::KB);
-        dst[0] = f2bf(h);
+        dst[0] = colq == 15 ? (uint16_t) kBf16One : f2bf(h);  // (column 15 = k 271: not a hidden unit, the bias rows' constant 1)
     };
     put_h(hbuf0, u0, hreg[0]);
     put_h(hbuf0, u1, hreg[1]);
@@ -479,15 +482,11 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
             hreg[q] = hnew;
             put_h(hn, u, hnew);
         };
-        // the recurrent chains start from b_hh (bf16 configuration: kns_device.hpp, gate_block_bf16)
-        auto acc_init = [&](f32x4 (&acc)[3], const int u) {
+        // the chains start from the inline constant 0: b_hh rides in the operands (two rows of the packed W_hh against h's constant 1)
+        auto acc_init = [&](f32x4 (&acc)[3], const int) {
 #pragma unroll
-            for (int gt = 0; gt < 3; ++gt) {
-                const float b = lbias[(u * 3 + gt) * 16 + colq];
-                acc[gt] = f32x4{b, b, b, b};
-            }
+            for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
         };
-
         KNS_STAMP(1);
         f32x4 acc[3];
         acc_init(acc, u0);
@@ -497,8 +496,7 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
         KNS_STAMP(3);
         acc_init(acc, u1);
         if (c16) {  // waves 1, 2, 3 also carry one gate of unit tile 16 (k-blocks in order in one accumulator) through this loop
-            const float b16 = lbias[(u2 * 3 + g16) * 16 + colq];
-            f32x4 a16 = f32x4{b16, b16, b16, b16};
+            f32x4 a16 = f32x4{0.f, 0.f, 0.f, 0.f};
             r8_tile_mma<kR8RegFrags1, R8C_Q, kR8RegFrags1, true>(acc, ha, w1, wl1w, lane, &a16, wl16 + g16 * 64 + lane);
             acc16[g16 * 64 + lane] = a16;
             // LDS operations of one wave complete in order: whoever sees the flag sees the accumulators
@@ -523,7 +521,7 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
                 const float ar = ((const float *) acc16)[(0 * 64 + lane) * 4 + e16];
                 const float az = ((const float *) acc16)[(1 * 64 + lane) * 4 + e16];
                 const float an = ((const float *) acc16)[(2 * 64 + lane) * 4 + e16];
-                h16 = gate_elem_bf16(xr, xz, xn, ar, az, an, h16);  // (the accumulators started from b_hh)
+                h16 = gate_elem_bf16(xr, xz, xn, ar, az, an, h16);
                 put_h16(hn, h16);
             }
         }

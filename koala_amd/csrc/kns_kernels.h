@@ -146,40 +146,33 @@ struct GruSmallArgs {
 };
 void launch_gru_small(const GruSmallArgs &a, hipStream_t s);
 
-// ---- a whole GRU layer over T frames in ONE launch: input GEMM + recurrent GEMM + gates fused over CU quads (kns_gruq.hip).
-// Four workgroups on one XCD own four m-tiles (64 streams); workgroup c keeps the columns of W_ih AND W_hh that belong to
-// hidden units 64 c .. 64 c + 63 resident in registers (every workgroup also keeps unit tile 16 and serves it for m-tile c),
-// computes its quarter of h' for all four m-tiles per step, and the quarters cross through L2 as self-tagged 8-byte granules.
-// The pre-activations never leave the CU: no `gi` round trip through HBM.
+// ---- a whole GRU layer of ONE frame in one launch: input GEMM + recurrent GEMM + gates fused over CU quads (kns_gruq.hip).
+// Four workgroups on one XCD own four m-tiles (64 streams); workgroup c pulls the columns of W_ih AND W_hh that belong to
+// hidden units 64 c .. 64 c + 63 (and serves unit tile 16 for m-tile c) and computes its quarter of h' for all four m-tiles.
 struct GruQuadArgs {
-    const void *a0;     // A-packed y_prev [T * mtiles][nb0] (null when nb0 == 0)
-    const void *a1;     // A-packed e or the previous layer's hidden sequence [T * mtiles][9]
+    const void *a0;     // A-packed y_prev [mtiles][nb0] (null when nb0 == 0)
+    const void *a1;     // A-packed e or the previous layer's hidden sequence [mtiles][9]
     const void *wih;    // B-packed [51][nb0 + 9]
     const float *bih;   // [51 * 16]
-    const void *whh;    // B-packed [51][9]
-    const float *bhh;   // [51 * 16]
+    const void *whh;    // B-packed [51][9] (with the bias rows, kns_layout.h kBiasK0)
+    const float *bhh;   // [51 * 16] (unused: the bias rides in whh)
     const float *hstate_in;   // C-packed fp32 [mtiles][17][64][4]
     float *hstate_out;
-    void *hseq;         // A-packed [T][mtiles][9], out
-    void *xchg;         // granule exchange buffer [mtiles][2][17][64][16 B]: {tag, 2 x bf16, tag, 2 x bf16} per lane
-    unsigned *err;      // [4] device words: first failure code of a launch (0 = none), see kns_gruq.hip
-    int nb0, T, mtiles;
-    unsigned serial;    // launch serial number (the high bits of every granule tag of this launch); never 0
+    void *hseq;         // A-packed [mtiles][9], out
+    int nb0, mtiles;
     int quad0 = 0;      // first quad of this launch (set by launch_gru_quad: 64 quads per launch)
-    unsigned long long *dbg = nullptr;  // developer build: [8 waves][4 T blocks][8] s_memtime stamps of workgroup `dbg_block`
+    unsigned long long *dbg = nullptr;  // developer build: [8 waves][4][8] s_memtime stamps of workgroup `dbg_block`
     int dbg_block = 0;
-    // one-frame calls (T == 1), optional: the narrow head of the PREVIOUS stage computed inside this launch instead of in a launch
-    // of its own -- y_prev = sigmoid(h_B . W_head + b_head) of the quad's four m-tiles, straight into the staged x operand; a0 is
-    // not read then
+    // optional: the narrow head of the PREVIOUS stage computed inside this launch instead of in a launch of its own -- y_prev =
+    // sigmoid(h_B . W_head + b_head) of the quad's four m-tiles, straight into the staged x operand; a0 is not read then
     const void *yh = nullptr;    // A-packed hidden sequence of the previous stage's layer B [mtiles][9]
     const void *yw = nullptr;    // B-packed head weights [2 nb0][9]
     const float *yb = nullptr;   // [2 nb0 * 16]
     int yvalid = 0;              // head width (columns >= yvalid are zero)
 };
-// true when the shape is one the fused kernel takes (bf16, T >= 1, m-tiles in whole quads)
+// true when the shape is one the fused kernel takes (bf16, m-tiles in whole quads)
 bool gru_quad_supported(int precision, int mtiles, int nb0);
 void launch_gru_quad(const GruQuadArgs &a, hipStream_t s);
-constexpr size_t kQuadXchgBytesPerMtile = 2 * 17 * 1024;
 
 // ---- state reset of selected streams
 struct ResetArgs {

@@ -35,6 +35,12 @@ constexpr int kGruLayers = 2 * kStages;
 // bf16 configuration: constants folded into the GRU weights and biases at pack time (r and z columns; n columns)
 constexpr float kGateScaleRZ = -1.44269504088896341f;  // -log2(e)
 constexpr float kGateScaleN = 2.88539008177792681f;    // 2 log2(e)
+// bf16 configuration: b_hh rides in the recurrent GEMM's operands -- rows kBiasK0 and kBiasK0 + 1 of the packed W_hh hold the bias
+// as a bf16 pair (hi = bf16(b), lo = bf16(b - hi): 16 significant bits) and the hidden-state operand carries the constant 1 at
+// those two k (they are padding of the last k-block, 271 -> 288).  The accumulators start from the inline constant 0: no
+// per-step bias fetch, no accumulator splats (round 4)
+constexpr int kBiasK0 = kHidden;          // = 271: column 15 of unit tile 16; kBiasK0 + 1 = 272: the first column past tile 16
+constexpr unsigned kBf16One = 0x3f80u;
 constexpr int kMaxFrontTaps = 5;         // KNS-v1.1: the front-end may see the last N <= 5 feature frames (the reference file has N = 5)
 
 enum Precision { kFp32 = 0, kBf16 = 1 };

@@ -259,7 +259,10 @@ __global__ __launch_bounds__(kFront ? 512 : 256, kFront ? 1 : 3) void analysis_k
 void launch_analysis(const AnalysisArgs &a, hipStream_t s) {
     dim3 grid(a.Bpad / 16, (a.T + a.seg - 1) / a.seg);
     const size_t roll = a.feat_hist ? (size_t) a.hist_slots * a.nbf * 1024 : 0;  // (one-frame calls: one workgroup per CU is plenty)
-    const size_t lds = kOffAEnd + 2 * 272 * 4 + (size_t) a.nbf * 1024 + roll;
+#ifndef KNS_STFT_LDS_PAD  // timing experiment: extra dynamic LDS per workgroup = fewer workgroups per CU
+#define KNS_STFT_LDS_PAD 0
+#endif
+    const size_t lds = kOffAEnd + 2 * 272 * 4 + (size_t) a.nbf * 1024 + roll + KNS_STFT_LDS_PAD;
     auto go = [&](auto kernel, int threads, size_t bytes) {
         if (bytes > 48 * 1024) (void) hipFuncSetAttribute((const void *) kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
         hipLaunchKernelGGL(kernel, grid, dim3(threads), bytes, s, a);
@@ -503,8 +506,11 @@ __global__ __launch_bounds__(kMaskIn ? 512 : 256, kMaskIn ? 1 : 3) void synthesi
 }
 
 void launch_synthesis(const SynthesisArgs &a, hipStream_t s) {
-    const size_t lds = kOffStftEnd;
+    const size_t lds = kOffStftEnd + KNS_STFT_LDS_PAD;
     const dim3 grid(a.Bpad / 16, (a.T + a.seg - 1) / a.seg);
+#if KNS_STFT_LDS_PAD
+    (void) hipFuncSetAttribute((const void *) synthesis_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+#endif
     if (a.mask_w && !a.recompute && a.mask_fp16 && a.T == 1)
         hipLaunchKernelGGL((synthesis_kernel<false, true, true>), grid, dim3(512), lds + kMaskTiles * 512, s, a);
     else if (a.recompute && a.mask_fp16)

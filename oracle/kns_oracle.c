@@ -126,6 +126,8 @@ typedef struct {
     float *w_ih_a, *b_ih_a, *w_hh_a, *b_hh_a; /* layer A: input [d_in + H] rows ordered [y_prev ; e] */
     float *w_ih_b, *b_ih_b, *w_hh_b, *b_hh_b; /* layer B: input H */
     float *w_head, *b_head;                   /* [H][d_out] */
+    /* bf16 mode: [H + 2][3H] = the (scaled, bf16-rounded) W_hh with the scaled b_hh appended as two bf16 rows hi, lo (malloc'd) */
+    float *w_hh_a_aug, *w_hh_b_aug;
 } kns_stage_t;
 
 struct kns_params {
@@ -164,6 +166,20 @@ static void tables_init(kns_params_t *p) {
         p->tw_re[n] = (float) cos(2.0 * pi * (double) n / KNS_NFFT);
         p->tw_im[n] = (float) -sin(2.0 * pi * (double) n / KNS_NFFT);
     }
+}
+
+/* bf16 mode: b_hh is part of the recurrent GEMM -- gh = [h ; 1 ; 1] . [W_hh ; b_hi ; b_lo], one
+ * chain from 0, with b_hi = bf16(b), b_lo = bf16(b - b_hi) (b already scaled): exactly what the engine packs (kns_engine.cpp,
+ * pk_hh) and every bf16 recurrent kernel computes (kns_layout.h, kBiasK0) */
+static float *augment_whh(const float *w_hh /* scaled, rounded */, const float *b_hh /* scaled */) {
+    float *a = (float *) malloc(sizeof(float) * (size_t) (KNS_H + 2) * KNS_G3);
+    memcpy(a, w_hh, sizeof(float) * (size_t) KNS_H * KNS_G3);
+    for (int c = 0; c < KNS_G3; ++c) {
+        const float hi = kns_round_bf16(b_hh[c]);
+        a[(size_t) KNS_H * KNS_G3 + c] = hi;
+        a[(size_t) (KNS_H + 1) * KNS_G3 + c] = kns_round_bf16(b_hh[c] - hi);
+    }
+    return a;
 }
 
 int kns_params_load(const char *path, int precision, kns_params_t **out) {
@@ -235,6 +251,10 @@ int kns_params_load(const char *path, int precision, kns_params_t **out) {
         TAKE_GRU(st->b_hh_b, 1, 0);
         TAKE(st->w_head, KNS_H * st->d_out, 1);
         TAKE(st->b_head, st->d_out, 0);
+        if (bf) {
+            st->w_hh_a_aug = augment_whh(st->w_hh_a, st->b_hh_a);
+            st->w_hh_b_aug = augment_whh(st->w_hh_b, st->b_hh_b);
+        }
     }
 #undef TAKE_GRU
 #undef TAKE
@@ -245,6 +265,10 @@ int kns_params_load(const char *path, int precision, kns_params_t **out) {
 
 void kns_params_free(kns_params_t *p) {
     if (!p) return;
+    for (int s = 0; s < KNS_STAGES; ++s) {
+        free(p->st[s].w_hh_a_aug);
+        free(p->st[s].w_hh_b_aug);
+    }
     free(p->blob);
     free(p);
 }
@@ -608,10 +632,20 @@ static void gemm_block(int nb, const float *x, int ldx, int K, const float *w, i
 
 /* one GRU layer step for a block of streams:  x [nb][K] -> h (in/out) [nb] pointers */
 static void gru_block(int nb, const float *x, int ldx, int K, const float *w_ih, const float *b_ih, const float *w_hh,
-                      const float *b_hh, float **h, int bf, float *gi, float *gh, float *hx) {
+                      const float *b_hh, const float *w_hh_aug, float **h, int bf, float *gi, float *gh, float *hx) {
     gemm_block(nb, x, ldx, K, w_ih, KNS_G3, b_ih, gi, KNS_G3, bf);
-    for (int s = 0; s < nb; ++s) memcpy(hx + (size_t) s * KNS_H, h[s], sizeof(float) * KNS_H);
-    gemm_block_b(nb, hx, KNS_H, KNS_H, w_hh, KNS_G3, b_hh, gh, KNS_G3, bf, bf /* bf16 mode: chains start from b_hh */);
+    if (bf) { /* gh = [h ; 1 ; 1] . [W_hh ; b_hi ; b_lo]: the bias is the last two links of the chain */
+        static const float zero[KNS_G3];
+        for (int s = 0; s < nb; ++s) {
+            memcpy(hx + (size_t) s * (KNS_H + 2), h[s], sizeof(float) * KNS_H);
+            hx[(size_t) s * (KNS_H + 2) + KNS_H] = 1.0f;
+            hx[(size_t) s * (KNS_H + 2) + KNS_H + 1] = 1.0f;
+        }
+        gemm_block_b(nb, hx, KNS_H + 2, KNS_H + 2, w_hh_aug, KNS_G3, zero, gh, KNS_G3, 1, 1 /* from 0 = the zero "bias" */);
+    } else {
+        for (int s = 0; s < nb; ++s) memcpy(hx + (size_t) s * KNS_H, h[s], sizeof(float) * KNS_H);
+        gemm_block_b(nb, hx, KNS_H, KNS_H, w_hh, KNS_G3, b_hh, gh, KNS_G3, 0, 0);
+    }
     for (int s = 0; s < nb; ++s) {
         float *gis = gi + (size_t) s * KNS_G3, *ghs = gh + (size_t) s * KNS_G3;
         for (int j = 0; j < KNS_H; ++j) {
@@ -619,6 +653,7 @@ static void gru_block(int nb, const float *x, int ldx, int K, const float *w_ih,
             if (bf) {
                 /* everything below lives in the pre-scaled domain (weights and biases carry -log2 e / 2 log2 e, scale_gates):
                  *   r = 1 / (1 + 2^(gi_r + gh_r))   z likewise   n = 1 - 2 / (1 + 2^(fma(r, gh_n, gi_n)))   h' = fma(z, h - n, n)
+                 * (gh already holds b_hh: it rode in the recurrent GEMM)
                  * -- the GPU's gate_block_bf16 (kns_device.hpp) with its hardware 2^x and reciprocal replaced by the spec's
                  * polynomial exponential and an IEEE division */
                 ir = kns_round_fp16(ir);
@@ -649,7 +684,7 @@ typedef struct {
     float xin[KNS_MAX_BLOCK][KNS_H + 64]; /* [y_prev ; e] */
     float e[KNS_MAX_BLOCK][KNS_H];
     float y[KNS_MAX_BLOCK][KNS_BINS];
-    float gi[KNS_MAX_BLOCK * KNS_G3], gh[KNS_MAX_BLOCK * KNS_G3], hx[KNS_MAX_BLOCK * KNS_H], xa[KNS_MAX_BLOCK * KNS_H];
+    float gi[KNS_MAX_BLOCK * KNS_G3], gh[KNS_MAX_BLOCK * KNS_G3], hx[KNS_MAX_BLOCK * (KNS_H + 2)], xa[KNS_MAX_BLOCK * KNS_H];
 } kns_scratch_t;
 
 /* one frame for a block of nb streams */
@@ -695,14 +730,14 @@ static void frame_block(const kns_params_t *p, int nb, kns_stream_t **st, const 
             memcpy(&w->xin[s][g->d_in], &w->e[s][0], sizeof(float) * KNS_H);
             hp[s] = st[s]->h[2 * sg];
         }
-        gru_block(nb, &w->xin[0][0], KNS_H + 64, K, g->w_ih_a, g->b_ih_a, g->w_hh_a, g->b_hh_a, hp, bf, w->gi, w->gh,
-                  w->hx);
+        gru_block(nb, &w->xin[0][0], KNS_H + 64, K, g->w_ih_a, g->b_ih_a, g->w_hh_a, g->b_hh_a, g->w_hh_a_aug, hp, bf, w->gi,
+                  w->gh, w->hx);
         /* layer B consumes layer A's new hidden state */
         for (int s = 0; s < nb; ++s) {
             memcpy(w->xa + (size_t) s * KNS_H, st[s]->h[2 * sg], sizeof(float) * KNS_H);
             hp[s] = st[s]->h[2 * sg + 1];
         }
-        gru_block(nb, w->xa, KNS_H, KNS_H, g->w_ih_b, g->b_ih_b, g->w_hh_b, g->b_hh_b, hp, bf, w->gi, w->gh, w->hx);
+        gru_block(nb, w->xa, KNS_H, KNS_H, g->w_ih_b, g->b_ih_b, g->w_hh_b, g->b_hh_b, g->w_hh_b_aug, hp, bf, w->gi, w->gh, w->hx);
         for (int s = 0; s < nb; ++s) memcpy(w->hx + (size_t) s * KNS_H, st[s]->h[2 * sg + 1], sizeof(float) * KNS_H);
         gemm_block(nb, w->hx, KNS_H, KNS_H, g->w_head, g->d_out, g->b_head, &w->y[0][0], KNS_BINS, bf);
         for (int s = 0; s < nb; ++s)

@@ -233,6 +233,32 @@ def test_device_call_in_place(random_model):
         assert np.array_equal(np.concatenate(got, axis=1), want)
 
 
+def test_host_call_in_place_through_the_pipelined_path(random_model):
+    """`enhanced` == `pcm` for a host-memory call large enough (>= 4 MiB, more frames than one sub-chunk) to be pipelined in
+    sub-chunks: exact aliasing is legal -- chunk c's copy-out lands on chunk c's own input columns, which are staged by then --
+    and gives the samples of a call with separate buffers; a PARTIAL overlap is refused with a message."""
+    B, T = 512, 32
+    x = synth_streams(B, T, seed=41)
+    kb = koala_amd.create_batch('key', B, T, 'bf16', model_path=random_model)
+    want = kb.process(x)
+    kb.reset()
+    buf = x.copy()
+    kb.process_into(buf, buf)
+    assert np.array_equal(buf, want)
+    kb.reset()
+    pin = kb.alloc_host(T)
+    pin[:] = x
+    kb.process_into(pin, pin)
+    assert np.array_equal(pin, want)
+    big = np.zeros((B + 1, T * 256), np.int16)
+    a, b = big[:B], big[1:]
+    a[:] = x
+    with pytest.raises(koala_amd.KoalaError) as e:
+        kb.process_into(a, b)
+    assert 'overlap' in str(e.value)
+    kb.delete()
+
+
 @pytest.mark.parametrize('B,Tmax,T,chunk', [(33, 32, 32, '16'), (33, 32, 21, '16'), (20, 8, 7, '4'), (48, 16, 16, '3'),
                                             (16, 32, 32, '0'), (5, 2, 2, '1')])
 def test_host_pointer_calls_are_pipelined_without_changing_results(random_model, monkeypatch, B, Tmax, T, chunk):
@@ -385,8 +411,8 @@ def test_alternative_kernels_give_identical_pcm(random_model, random5_model):
                                'lib': DEV_LIB}
     for switch in ('', 'KOALA_AMD_GRU_STREAM', 'KOALA_AMD_GEMM_GENERIC',
                    'KOALA_AMD_GEMM_NO_WSR', 'KOALA_AMD_NO_SMALL', 'KOALA_AMD_NO_GRAPH', 'KOALA_AMD_STORE_SPECTRUM',
-                   'KOALA_AMD_DEBUG_TAPS', 'KOALA_AMD_QUAD', 'KOALA_AMD_NO_QUAD', 'KOALA_AMD_NO_HEAD_FUSE', 'KOALA_AMD_NO_STFT_FUSE'):  # (GRU layers as one launch fused over CU quads,
-        # kns_gruq.hip: everywhere / nowhere; the product takes it for one-frame calls of large batches)
+                   'KOALA_AMD_DEBUG_TAPS', 'KOALA_AMD_NO_QUAD', 'KOALA_AMD_NO_HEAD_FUSE', 'KOALA_AMD_NO_STFT_FUSE'):  # (KOALA_AMD_NO_QUAD: one-frame calls of large
+        # batches through input GEMM + recurrent kernel instead of the one-step quad kernel, kns_gruq.hip)
         env = dict(os.environ)
         if switch:
             env[switch] = '1'

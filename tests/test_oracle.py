@@ -286,3 +286,14 @@ def test_front_end_context_extension(random_model, tmp_path):
     lib.pv_get_error_stack(C.byref(ref), C.byref(depth))
     assert b'front-end over 6 feature frames' in ref[0]
     lib.pv_free_error_stack(ref)
+    # the word is unsigned: a value with the top bit set is refused too (as an int it would be a negative count that passes a
+    # signed `> 5` test and sizes a vector: an exception across the C ABI) -- by the engine's loader and by the oracle's
+    raw[8 + 11 * 4:8 + 12 * 4] = (0x80000005).to_bytes(4, 'little')
+    p7 = str(tmp_path / 'taps_msb.kns')
+    open(p7, 'wb').write(bytes(raw))
+    assert lib.pv_koala_init(b'key', p7.encode(), b'best', C.byref(h)) == 2
+    lib.pv_get_error_stack(C.byref(ref), C.byref(depth))
+    assert b'front-end over 2147483653 feature frames' in ref[0]
+    lib.pv_free_error_stack(ref)
+    with pytest.raises(IOError):
+        oracle.Oracle(p7)
