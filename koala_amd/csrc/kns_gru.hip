@@ -449,8 +449,14 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     // waves 0..3 use them): with conditional loads and stores in the loop hipcc's first vmcnt wait of a step also covered
     // the pre-activations requested last in the previous step.
     const unsigned lane8 = lane * 8u;
-    auto publish = [&](const frag_t *src, int slot) {
-        const __amdgpu_buffer_rsrc_t hs = make_rsrc((const frag_t *) g.hseq + ((size_t) slot * g.mtiles + mt) * NBH * 64, NBH * 1024);
+    // The bases of the two per-step streams are ADVANCED by their stride instead of being recomputed from t (hipcc does not
+    // strength-reduce the 64-bit (t * mtiles + mt) * bytes products: ~40 scalar instructions per step in a loop whose waves issue
+    // an instruction every ~5 cycles): the hidden-sequence slot of step t is max(t - 1, 0), the pre-activation slot min(t + 1, T - 1)
+    const size_t hs_stride = (size_t) g.mtiles * NBH * 1024, gi_stride = (size_t) g.mtiles * kGateTiles * 512;
+    const char *hs_base = (const char *) g.hseq + (size_t) mt * NBH * 1024;
+    const char *gn_base = (const char *) g.gi + (size_t) mt * kGateTiles * 512 + (g.T > 1 ? gi_stride : 0);
+    auto publish = [&](const frag_t *src, const char *slot_base) {
+        const __amdgpu_buffer_rsrc_t hs = make_rsrc(slot_base, NBH * 1024);
         const unsigned i0 = wave * 64 + lane, i1 = 8 * 64 + wave * 8 + (lane & 7);
         const frag_t x0 = src[i0];
         buf_store_frag(hs, i0 * 16u, x0);
@@ -464,9 +470,10 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
         const char *hc = (t & 1) ? hbuf1 : hbuf0;
         char *hn = (t & 1) ? hbuf0 : hbuf1;
         const frag_t *ha = (const frag_t *) hc;
-        publish(ha, t > 0 ? t - 1 : 0);  // LDS holds h_{t-1}
-        const __amdgpu_buffer_rsrc_t gnext = make_rsrc(
-            (const P::gi_t *) g.gi + ((size_t) (t + 1 < g.T ? t + 1 : t) * g.mtiles + mt) * kGateTiles * 64, kGateTiles * 512);
+        publish(ha, hs_base);  // LDS holds h_{t-1}
+        const __amdgpu_buffer_rsrc_t gnext = make_rsrc(gn_base, kGateTiles * 512);
+        hs_base += t > 0 ? hs_stride : 0;
+        gn_base += t + 2 < g.T ? gi_stride : 0;
 
         auto gates = [&](const int q, f32x4 (&acc)[3]) {
             // the fp16 pre-activations enter the gate arithmetic through v_fma_mix_f32 (an f16 operand of an f32 fma): x + t as
@@ -529,7 +536,7 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
         __syncthreads();
         KNS_STAMP(8);
     }
-    publish((const frag_t *) ((g.T & 1) ? hbuf1 : hbuf0), g.T - 1);
+    publish((const frag_t *) ((g.T & 1) ? hbuf1 : hbuf0), (const char *) g.hseq + ((size_t) (g.T - 1) * g.mtiles + mt) * NBH * 1024);
     ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u0) * 64 + lane] = hreg[0];
     ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u1) * 64 + lane] = hreg[1];
     if (q16) g.hstate_out[(((size_t) mt * kUnitTiles + u2) * 64 + lane) * 4 + e16] = h16;
