@@ -410,6 +410,22 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
 
+    # one rank per GPU on one node: every rank keeps to its own slice of the host cores (its Python thread, the engine's
+    # pageable-path copy threads and RCCL's proxy thread then never migrate onto a sibling's cores).  KOALA_BENCH_NO_AFFINITY=1
+    # leaves the scheduler alone.
+    cores_per_rank = None
+    if world > 1 and not os.environ.get('KOALA_BENCH_NO_AFFINITY') and hasattr(os, 'sched_setaffinity'):
+        try:
+            cores = sorted(os.sched_getaffinity(0))
+            local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+            lr = int(os.environ.get('LOCAL_RANK', '0'))
+            if len(cores) >= local_world:
+                mine = cores[lr * len(cores) // local_world:(lr + 1) * len(cores) // local_world]
+                os.sched_setaffinity(0, mine)
+                cores_per_rank = len(mine)
+        except OSError:
+            pass
+
     koala_amd.build_native()
     model = params.ensure_params(os.path.join(ROOT, 'build', 'random_1234.kns'), 'random', 1234)
     B, T = args.streams, args.frames
@@ -476,9 +492,12 @@ def main():
     # ---- per-kernel pass (same workload, HIP events around every launch on the engine's stream)
     prof_steps = max(2, min(args.steps, 20))
     kb.profile_enable(True)
+    torch.cuda.synchronize()
+    t_prof = time.perf_counter()
     for _ in range(prof_steps):
         step()
-    prof = kb.profile_read()
+    prof = kb.profile_read()  # (synchronises)
+    instrumented_ms_per_step = (time.perf_counter() - t_prof) / prof_steps * 1e3
     kb.profile_enable(False)
     frames_per_launch = B * T
     work = {
@@ -566,28 +585,39 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
         ncores = os.cpu_count() or 1
+        # the timed leg runs the oracle compiled for THIS host's instruction set (-march=native, built here and now; the parity
+        # checks below use the portable build that travels with the repository: same source, same results bit for bit) and
+        # starts once the box is quiet -- the 1-minute load average below 4, waited for at most 45 s (it decays with a 60 s time
+        # constant: after the GPU legs' host threads it starts around 15-30)
+        native = oracle.build_native()
+        t_wait = time.perf_counter()
+        while machine_state().get('loadavg_1m', 0.0) >= 4.0 and time.perf_counter() - t_wait < 45.0:
+            time.sleep(1.0)
+        waited = time.perf_counter() - t_wait
         before = machine_state()
+        before['waited_for_quiet_s'] = round(waited, 1)
         # calibrate, then size the sample for ~10-20 s of CPU work
-        o = oracle.Oracle(model, 1024, oracle.PREC_FP32)
+        o = oracle.Oracle(model, 1024, oracle.PREC_FP32, library=native)
         xs = np.ascontiguousarray(x[:1024, :8 * 256]) if B >= 1024 else np.ascontiguousarray(np.tile(base, (16, 1))[:1024, :8 * 256])
         c0 = time.perf_counter()
         o.process(xs)
         rate = 1024 * 8 / (time.perf_counter() - c0)
         ns = int(min(16384, max(64, (rate * 15) // (T * 64) * 64)))
-        o = oracle.Oracle(model, ns, oracle.PREC_FP32)
+        o = oracle.Oracle(model, ns, oracle.PREC_FP32, library=native)
         xs = np.ascontiguousarray(np.tile(base, ((ns + distinct - 1) // distinct, 1))[:ns])
         c0 = time.perf_counter()
         o.process(xs)
         dt = time.perf_counter() - c0
         # one thread, for scale: the multi-thread figure is a weak baseline (shared weights, 64-stream blocks per thread)
         n1 = 64
-        o1 = oracle.Oracle(model, n1, oracle.PREC_FP32)
+        o1 = oracle.Oracle(model, n1, oracle.PREC_FP32, library=native)
         x1 = np.ascontiguousarray(np.tile(base, ((n1 + distinct - 1) // distinct, 1))[:n1, :16 * 256])
         c1 = time.perf_counter()
         o1.process(x1, 1)
         rate1 = n1 * 16 / (time.perf_counter() - c1)
         cpu = {'value': round(ns * T / dt, 1), 'unit': 'frames/s', 'cores': ncores, 'kind': 'port',
                'one_thread_frames_per_s': round(rate1, 1), 'scaling_vs_1_thread': round(ns * T / dt / rate1, 1),
+               'build': '-O3 -march=native (this host)' if native.endswith('_native.so') else '-O3 -march=x86-64-v3',
                'sample': '%d streams x %d frames of the same synthetic workload, oracle/kns_oracle.c fp32 (register-blocked '
                          'k-ascending fmaf GEMMs, OpenMP over stream blocks of %d), %.1f s'
                          % (ns, T, oracle.block_size(), dt),
@@ -609,6 +639,14 @@ def main():
         parity['mask_rms_vs_fp32_oracle'] = float('%.3e' % np.sqrt(np.mean(dm * dm)))
         parity['mask_max_abs_vs_fp32_oracle'] = float('%.3e' % np.abs(dm).max())
         parity['mask_rms_bar'] = 1e-3
+        # the bars of the timed configuration: bf16 -- the spec's tolerance: at most 5 LSB against the
+        # oracle with the same rounding points, >= 99.9 % of the samples within 1 LSB, mask within 1e-3 RMS of the fp32 path;
+        # fp32 -- the oracle's samples.  A run that misses one prints its line and FAILS (exit status 3).
+        bars = {'max_lsb': 5, 'within_1_lsb': 0.999, 'mask_rms': 1e-3} if args.precision == 'bf16' else \
+               {'max_lsb': 0, 'within_1_lsb': 1.0, 'mask_rms': 1e-3}
+        parity['bars'] = bars
+        parity['pass'] = bool(parity['max_lsb'] <= bars['max_lsb'] and parity['within_1_lsb'] >= bars['within_1_lsb'] and
+                              parity['mask_rms_vs_fp32_oracle'] < bars['mask_rms'])
     if rank == 0 and world == 1 and not args.no_extra:
         extra = extra_points(args, torch, np, koala_amd, model, kb, x, dx, dy, base, local_rank)
     # the constants the fractions are divided by, next to what a plain device-to-device copy reaches on this box
@@ -653,18 +691,26 @@ def main():
             'streams_per_gpu': B, 'frames_per_call': T, 'global_streams': B * world,
             'parallelism': 'streams sharded over %d GPU(s), no data-path collective' % world,
             'throughput_all_reduce': collective,  # 'nccl' (= RCCL) under a launcher, None for a plain single-process run
+            'host_cores_per_rank': cores_per_rank,
         },
         'real_time_factor': round(elapsed_max / (args.steps * T * 256 / 16000.0) / B, 9),
         'frames_per_sec_per_gpu': round(value / world, 1),
         'roofline': roofline,
         'peaks': peaks,
         'stages': stages,
+        # the per-class times above come from a SECOND pass with a HIP event pair around every launch; that pass runs a few per
+        # cent slower than the timed one (the events serialise the launches): both step times, so the shares can be scaled
+        'stages_pass': {'ms_per_step': round(instrumented_ms_per_step, 4), 'sum_of_class_ms': round(dev_ms, 4),
+                        'timed_ms_per_step': round(elapsed_max / args.steps * 1e3, 4)},
         'cpu_baseline': cpu,
         'parity': parity,
         'extra': extra,
     }
     print(json.dumps(line))
     sys.stdout.flush()
+    if parity is not None and not parity['pass']:
+        print('bench.py: the timed engine misses its parity bars: %r' % (parity,), file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == '__main__':

@@ -580,6 +580,37 @@ bool Engine::reset(const uint8_t *host_mask, std::string *err) {
     return true;
 }
 
+// ---- dispatch: which kernel family a call takes (mtb = m-tiles of 16 streams = ceil(B / 16); edges measured on MI355X, each
+// tested from both sides by tests/test_gpu_parity.py::test_dispatch_boundaries; the developer build reports the route of the
+// last call through debug tap 6, tests/test_gpu_parity.py::test_dispatch_routes)
+//
+//   GRU layers (8 per call)
+//   | configuration | frames T | m-tiles mtb                           | route                                                        |
+//   |---------------|----------|---------------------------------------|--------------------------------------------------------------|
+//   | bf16          | 1        | <= 59, or not whole quads up to 192   | kRouteSmall: gru_small_kernel, one launch per layer           |
+//   | bf16          | 1        | >= 60 and mtb % 4 == 0                | kRouteQuad1: gru_quad1_kernel, one launch per layer; stage    |
+//   |               |          |                                       |   inputs wider than 2 k-blocks: input GEMM + recurrent kernel |
+//   | bf16          | 1        | > 192 and mtb % 4 != 0                | kRouteChunked                                                 |
+//   | bf16          | > 1      | any                                   | kRouteChunked: gemm_ws2 (m-tiles in multiples of 256 x stage; |
+//   |               |          |                                       |   the rest through gemm_kernel) + gru_resident8_kernel        |
+//   | fp32          | 1        | <= 256                                | kRouteSmall                                                   |
+//   | fp32          | 1        | > 256                                 | kRouteChunked: gemm_kernel + gru_kernel<PF32, 8>              |
+//   | fp32          | > 1      | <= 192                                | kRouteSmallSteps: gru_small_kernel frame by frame (T launches |
+//   |               |          |                                       |   per layer; the chunked recurrence would occupy mtb CUs)     |
+//   | fp32          | > 1      | > 192                                 | kRouteChunked                                                 |
+//
+//   Around them (all configurations)
+//   | what                          | T = 1, bf16                                         | otherwise                            |
+//   |-------------------------------|-----------------------------------------------------|--------------------------------------|
+//   | spectrum                      | stored by analysis, read by synthesis (in place)    | T > 1: rebuilt from the PCM by the   |
+//   |                               |                                                     | synthesis kernel (not if in == out)  |
+//   | front-end GEMM                | inside the analysis launch (one-frame front-end)    | gemm_wsr / gemm_front5 / gemm_kernel |
+//   | narrow heads 1 / 5 / 40       | inside the next stage's first layer launch          | gemm_head_kernel                     |
+//   | mask head                     | inside the synthesis launch                         | gemm_wsr_kernel                      |
+//   | analysis / synthesis segments | one                                                 | ~4 / ~2 workgroups per CU (>= 4 frames) |
+//   Host-pointer calls: >= 4 MiB and more than min(16, max_frames / 2) frames -> sub-chunks on three streams; T = 1 -> hipGraph replay.
+enum Route { kRouteChunked = 0, kRouteSmall = 1, kRouteSmallSteps = 2, kRouteQuad1 = 3 };
+
 bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string *err, bool allow_recompute) {
     const int mtb = Bpad_ / 16;
     const int M = mtb * T;
@@ -764,6 +795,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         tock(kClsGru);
     };
 
+    last_route_ = small ? kRouteSmall : small_steps ? kRouteSmallSteps : quad ? kRouteQuad1 : kRouteChunked;
     // front-end: e = features . W_in + b_in
     if (!front_in_analysis)
         gemm(kClsGemmHead, nullptr, 0, roll_in_analysis ? d_fhist_ : d_feat_, nbf_, w_in_, b_in_, d_e_, nbh_ * pi_.npb, kHidden, kOutAPlain,
@@ -1156,6 +1188,15 @@ int64_t Engine::debug_read(int what, float *out, int64_t capacity, std::string *
                 for (int k = 0; k < kHidden; ++k)
                     out[((size_t) l * B_ + b) * kHidden + k] =
                         s[(((size_t) l * mtb + b / 16) * kUnitTiles + k / 16) * 256 + cpack_off(b % 16, k % 16)];
+#ifdef KNS_DEV
+    } else if (what == 6) {  // developer build: the route of the last call (enum Route), what rode inside other launches
+        if (capacity < 4) return -2;
+        out[0] = (float) last_route_;
+        out[1] = feat_valid_ ? 0.0f : 1.0f;   // front-end inside the analysis launch / features rolled into the history
+        out[2] = mask_valid_ ? 0.0f : 1.0f;   // mask head inside the synthesis launch
+        out[3] = spec_valid_ ? 1.0f : 0.0f;   // spectrum stored (not recomputed)
+        return 4;
+#endif
     } else if (what == 5) {  // developer build: stamps of the last fused layer launch, [8 waves][4 T][8] ticks since the first one
         if (!d_qdbg_) {
             *err = "no stamps: developer build with KOALA_AMD_QUAD_DBG=<workgroup>";

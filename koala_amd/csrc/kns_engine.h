@@ -116,6 +116,7 @@ private:
     int qdbg_block_ = -1;
     // the last run_device() stored the spectrum / the features / the mask (debug_read refuses a tap that was not stored)
     bool spec_valid_ = false, feat_valid_ = false, mask_valid_ = false;
+    int last_route_ = 0;  // enum Route of the last run_device() (kns_engine.cpp; reported by the developer build's debug tap 6)
 
     // profiling
     bool profiling_ = false;

@@ -228,13 +228,18 @@ PV_API const char *pv_status_to_string(pv_status_t status) {
 PV_API pv_status_t pv_get_error_stack(char ***message_stack, int32_t *message_stack_depth) {
     if (!message_stack || !message_stack_depth) return PV_STATUS_INVALID_ARGUMENT;
     const size_t n = t_stack.size();
+    if (n == 0) {  // nothing pending: no allocation either -- a caller that sees a failure status frees nothing (found by the ASan build)
+        *message_stack = NULL;
+        *message_stack_depth = 0;
+        return PV_STATUS_INVALID_STATE;
+    }
     char **arr = (char **) calloc(n + 1, sizeof(char *));
     if (!arr) return PV_STATUS_OUT_OF_MEMORY;
     for (size_t i = 0; i < n; ++i) arr[i] = strdup(t_stack[i].c_str());
     t_stack.clear();
     *message_stack = arr;
     *message_stack_depth = (int32_t) n;
-    return n ? PV_STATUS_SUCCESS : PV_STATUS_INVALID_STATE;
+    return PV_STATUS_SUCCESS;
 }
 
 PV_API void pv_free_error_stack(char **message_stack) {

@@ -30,28 +30,47 @@ class _Taps(C.Structure):
     _fields_ = [(n, C.POINTER(C.c_float)) for n in ("spectrum", "features", "embed", "heads", "hidden")]
 
 
+def build_native() -> str:
+    """The same source compiled -march=native on THIS host (bench.py's cpu_baseline leg); falls back to the portable build.
+    Always rebuilt (-B): a copy made on another machine may use instructions this one lacks (it is .gpurunignore'd as well)."""
+    path = os.path.join(_HERE, "libkns_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libkns_oracle_native.so"])
+        return path
+    except Exception:
+        return build()
+
+
 _lib = None
+_libs = {}
 
 
-def lib():
+def lib(path=None):
     global _lib
+    if path is not None:
+        if path not in _libs:
+            _libs[path] = _bind(C.CDLL(path))
+        return _libs[path]
     if _lib is None:
-        l = C.CDLL(build())
-        l.kns_params_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
-        l.kns_params_free.argtypes = [C.c_void_p]
-        l.kns_oracle_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
-        l.kns_oracle_delete.argtypes = [C.c_void_p]
-        l.kns_oracle_reset.argtypes = [C.c_void_p, C.c_void_p]
-        l.kns_oracle_process.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
-        l.kns_oracle_process_mask.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
-        l.kns_oracle_process_tap.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(_Taps)]
-        l.kns_oracle_analysis.argtypes = [C.c_void_p] * 5
-        l.kns_oracle_synthesis.argtypes = [C.c_void_p] * 4
-        for n in ("kns_exp", "kns_log", "kns_sigmoid", "kns_tanh", "kns_round_bf16", "kns_round_fp16"):
-            getattr(l, n).argtypes = [C.c_float]
-            getattr(l, n).restype = C.c_float
-        _lib = l
+        _lib = _bind(C.CDLL(build()))
     return _lib
+
+
+def _bind(l):
+    l.kns_params_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    l.kns_params_free.argtypes = [C.c_void_p]
+    l.kns_oracle_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    l.kns_oracle_delete.argtypes = [C.c_void_p]
+    l.kns_oracle_reset.argtypes = [C.c_void_p, C.c_void_p]
+    l.kns_oracle_process.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    l.kns_oracle_process_mask.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    l.kns_oracle_process_tap.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(_Taps)]
+    l.kns_oracle_analysis.argtypes = [C.c_void_p] * 5
+    l.kns_oracle_synthesis.argtypes = [C.c_void_p] * 4
+    for n in ("kns_exp", "kns_log", "kns_sigmoid", "kns_tanh", "kns_round_bf16", "kns_round_fp16"):
+        getattr(l, n).argtypes = [C.c_float]
+        getattr(l, n).restype = C.c_float
+    return l
 
 
 def block_size() -> int:
@@ -66,8 +85,8 @@ def _ptr(a):
 class Oracle:
     """`num_streams` independent KNS-v1 streams on the host CPU."""
 
-    def __init__(self, model_path: str, num_streams: int = 1, precision: int = PREC_FP32):
-        self._l = lib()
+    def __init__(self, model_path: str, num_streams: int = 1, precision: int = PREC_FP32, library: str = None):
+        self._l = lib(library)
         self._params = C.c_void_p()
         rc = self._l.kns_params_load(model_path.encode(), precision, C.byref(self._params))
         if rc != 0:

@@ -618,3 +618,20 @@ def test_dispatch_boundaries(random_model, precision, B, T):
         for i in range(128, B):  # replicas in other m-tiles (the last one ragged at 272 / 3088) are bit-identical
             assert np.array_equal(y[i], y[i % 128]), i
     kb.delete()
+
+
+@pytest.mark.parametrize('precision,B,T,route', [('bf16', 16, 1, 1), ('bf16', 944, 1, 1), ('bf16', 960, 1, 3), ('bf16', 976, 1, 1),
+                                                 ('bf16', 3072, 1, 3), ('bf16', 3088, 1, 0), ('bf16', 4096, 1, 3), ('bf16', 64, 4, 0),
+                                                 ('bf16', 4096, 4, 0), ('fp32', 256, 1, 1), ('fp32', 4096, 1, 1), ('fp32', 4112, 1, 0),
+                                                 ('fp32', 256, 4, 2), ('fp32', 3072, 2, 2), ('fp32', 3088, 2, 0)])
+def test_dispatch_routes(random_model, precision, B, T, route):
+    """The dispatch table at the head of Engine::run_device (kns_engine.cpp), row by row: the developer build says which kernel
+    family the last call took (0 chunked, 1 low-latency layer kernel, 2 the same frame by frame, 3 one-step quad kernel) and what
+    rode inside other launches."""
+    kb = koala_amd.create_batch('key', B, T, precision, model_path=random_model, library_path=DEV_LIB)
+    kb.process(synth_streams(B, T, seed=1))
+    got = kb.debug_read('route', T)
+    kb.delete()
+    assert int(got[0]) == route, got.tolist()
+    fused = precision == 'bf16' and T == 1
+    assert bool(got[1]) == fused and bool(got[2]) == fused and bool(got[3]) == (T == 1)

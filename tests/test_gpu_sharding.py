@@ -91,6 +91,26 @@ def test_bench_launches_its_own_ranks():
     assert abs(line['value'] - 1024 * 8 * 3 / (line['ms_per_step'] * 3e-3)) / line['value'] < 1e-3
 
 
+def test_eight_ranks_like_configs3():
+    """BASELINE configs[3]'s shape on the one GPU this box has: EIGHT ranks (separate processes and HIP contexts, all on GPU 0,
+    gloo in place of RCCL) x 512 streams each -- an 8-way rendezvous, `shard_range(8 * 512, r, 8)` per rank, per-rank host-core
+    sets, max-over-ranks timing, and the aggregate of all eight on the line.  (On an 8-GPU node the driver runs the same command
+    without KOALA_BENCH_SHARE_GPU and with the nccl backend: one engine and one GPU per rank.)"""
+    env = dict(os.environ, KOALA_BENCH_SHARE_GPU='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--dist-backend', 'gloo', '--steps', '3',
+                          '--warmup', '1', '--prime-seconds', '0', '--sustain-seconds', '0', '--streams', '512', '--frames', '8',
+                          '--no-cpu-baseline', '--no-extra'], env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 8 and line['config']['global_streams'] == 8 * 512 and line['scaling'] == 'weak'
+    assert abs(line['value'] - 8 * 512 * 8 * 3 / (line['ms_per_step'] * 3e-3)) / line['value'] < 1e-3
+    assert abs(line['frames_per_sec_per_gpu'] * 8 - line['value']) / line['value'] < 1e-3
+    aff = line['config']['host_cores_per_rank']
+    assert aff is None or aff >= 1
+
+
 def test_rccl_branch_runs_with_one_rank_under_torchrun():
     """The driver starts multi-GPU runs as `python -m torch.distributed.run ... bench.py --gpus N` with backend nccl (= RCCL).
     A one-GPU box cannot host two RCCL ranks, but it can host ONE: communicator creation on the device
