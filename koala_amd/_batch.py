@@ -132,7 +132,7 @@ class KoalaBatch(object):
         shapes = {'features': (0, (num_frames, self.num_streams, 257)), 'spectrum': (1, (num_frames, self.num_streams, 257, 2)),
                   'mask': (2, (num_frames, self.num_streams, 257)), 'hidden': (3, (8, self.num_streams, 271)),
                   'embed': (4, (num_frames, self.num_streams, 271)),
-                  'route': (6, (4,))}  # developer library only: [route, front-end fused, mask head fused, spectrum stored]
+                  'route': (6, (4,))}  # developer library only: [route, features not stored, mask head fused, spectrum stored]
         code, shape = shapes[what]
         out = np.empty(shape, np.float32)
         n = self._lib.pv_koala_batch_debug_read(self._handle, code, out.ctypes.data, out.size)

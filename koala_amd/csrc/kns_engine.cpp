@@ -60,6 +60,11 @@ LoadResult load_params(const char *path, Params *p, std::string *err) {
                std::to_string(kMaxFrontTaps) + " are supported).";
         return kLoadFormat;
     }
+    if (hdr[12] != 0) {  // the CPU oracle's fixed-point emulation (tools/pv_hypotheses.py): not an engine feature
+        fclose(f);
+        *err = std::string("`") + path + "` asks for re-quantised pre-activations (KNS1 header word 12), which only the CPU oracle emulates.";
+        return kLoadFormat;
+    }
     const size_t G3 = 3 * kHidden;
     ok = read_vec(f, &p->mean, kBins) && read_vec(f, &p->scale, kBins) &&
          read_vec(f, &p->w_in, (size_t) p->front_taps * kBins * kHidden) && read_vec(f, &p->b_in, kHidden);
@@ -241,6 +246,7 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     nbf_ = ceil_div(kBins, pi_.kb);
     nbh_ = ceil_div(kHidden, pi_.kb);
     taps_ = p.front_taps;
+    fold_ = precision == kBf16 && taps_ == 1;  // the front-end rides in the stage-input GEMMs (see the packing below)
     if (hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking) != hipSuccess) {
         (void) hipGetLastError();
         *err = "Failed to create a HIP stream.";
@@ -308,7 +314,7 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
 
     // ---- weights, pre-packed into MFMA B-fragment order
     const int G3 = 3 * kHidden;
-    {
+    if (!fold_) {
         auto tiles = dense_tiles(kHidden, pi_.npb);
         std::vector<Seg> segs;  // one segment per stacked feature frame, oldest first: each padded to whole k-blocks like the features
         for (int i = 0; i < p.front_taps; ++i) segs.push_back({i * kBins, kBins});
@@ -361,11 +367,40 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
             auto img = pack_b(aug.data(), G3, {{0, kHidden + 2}}, gt, precision);
             return upload(img.data(), img.size());
         };
-        d.w_ih_a = pk(st.w_ih_a, segs_a);
+        if (fold_) {
+            // bf16 configuration, one-frame front-end: the front-end is linear and only the stage-input
+            // GEMMs consume its output, so it is FOLDED into them -- with W_e the embedding rows of this stage's gate-scaled, unrounded
+            // W_ih:  Wc[k][n] = sum_j w_in[k][j] W_e[j][n],  b'[n] = b_ih[n] + sum_j b_in[j] W_e[j][n]  (j ascending fmaf chains from 0, in
+            // fp32), THEN rounded to bf16.  Stage input = [y_prev ; features]; the embedding is never formed.  (oracle: fold_front)
+            const std::vector<float> ws = gate_scaled(st.w_ih_a, (size_t) st.d_in + kHidden), bs = gate_scaled(st.b_ih_a, 1);
+            std::vector<float> wf((size_t) (st.d_in + kBins) * G3, 0.0f), bf(G3, 0.0f);
+            memcpy(wf.data(), ws.data(), sizeof(float) * (size_t) st.d_in * G3);
+            const float *we = ws.data() + (size_t) st.d_in * G3;
+            for (int k = 0; k < kBins; ++k) {
+                float *row = wf.data() + (size_t) (st.d_in + k) * G3;
+                for (int j = 0; j < kHidden; ++j) {
+                    const float a = p.w_in[(size_t) k * kHidden + j];
+                    const float *wr = we + (size_t) j * G3;
+                    for (int n = 0; n < G3; ++n) row[n] = __builtin_fmaf(a, wr[n], row[n]);
+                }
+            }
+            for (int j = 0; j < kHidden; ++j)
+                for (int n = 0; n < G3; ++n) bf[n] = __builtin_fmaf(p.b_in[j], we[(size_t) j * G3 + n], bf[n]);
+            for (int n = 0; n < G3; ++n) bf[n] = bs[n] + bf[n];
+            std::vector<Seg> segs_f;
+            if (st.d_in) segs_f.push_back({0, st.d_in});
+            segs_f.push_back({st.d_in, kBins});
+            auto img = pack_b(wf.data(), G3, segs_f, gt, precision);
+            d.w_ih_a = upload(img.data(), img.size());
+            auto bimg = pack_bias(bf.data(), gt);
+            d.b_ih_a = (float *) upload(bimg.data(), bimg.size() * 4);
+        } else {
+            d.w_ih_a = pk(st.w_ih_a, segs_a);
+            d.b_ih_a = pb(st.b_ih_a);
+        }
         d.w_hh_a = pk_hh(st.w_hh_a, st.b_hh_a);
         d.w_ih_b = pk(st.w_ih_b, {{0, kHidden}});
         d.w_hh_b = pk_hh(st.w_hh_b, st.b_hh_b);
-        d.b_ih_a = pb(st.b_ih_a);
         d.b_hh_a = pb(st.b_hh_a);
         d.b_ih_b = pb(st.b_ih_b);
         d.b_hh_b = pb(st.b_hh_b);
@@ -403,7 +438,7 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
         // configurations (the bf16 one takes its logarithm from v_log_f32, which no host formula reproduces)
         d_silent_ = dalloc((size_t) nbf_ * 1024, true);
     }
-    d_e_ = dalloc(M * nbh_ * 1024, true);
+    if (!fold_) d_e_ = dalloc(M * nbh_ * 1024, true);
     for (int s = 0; s < kStages - 1; ++s) d_y_[s] = dalloc(M * nby_[s] * 1024, true);
     d_gi_ = dalloc(M * kGateTiles * 64 * pi_.gisz, true);
     d_hseq_a_ = dalloc(M * nbh_ * 1024, true);
@@ -660,17 +695,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         while (seg > 4 && (Bpad_ / 16) * ((T + seg - 1) / seg) < 1024) seg = (seg + 1) / 2;
         an.seg = seg_env > 0 ? (seg_env < T ? seg_env : T) : seg;
     }
-    // One-frame calls (bf16, one-frame front-end): the front-end GEMM rides in the analysis launch (kns_stft.hip, kFront) -- the
-    // feature tile never leaves the CU and a frame step is one launch shorter.
-    const bool front_in_analysis = T == 1 && prec_ == kBf16 && taps_ == 1 && fuse_front_ && !debug_taps_ && an.write_spec;
-    if (front_in_analysis) {
-        an.front_w = w_in_;
-        an.front_b = b_in_;
-        an.front_out = d_e_;
-        an.front_valid = kHidden;
-        an.feat = nullptr;
-    }
-    feat_valid_ = !front_in_analysis && !roll_in_analysis;  // (otherwise the feature tile never left the CU / went to the history slots)
+    feat_valid_ = !roll_in_analysis;  // (otherwise the features went to the history slots)
     const int16_t *hist_before = d_hist_[hist_cur_];
     const int only = dev_only_class_;  // -1 in the product library
     tick(kClsAnalysis);
@@ -797,9 +822,11 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
 
     last_route_ = small ? kRouteSmall : small_steps ? kRouteSmallSteps : quad ? kRouteQuad1 : kRouteChunked;
     // front-end: e = features . W_in + b_in
-    if (!front_in_analysis)
+    // (bf16 with a one-frame front-end: folded into the stage-input GEMMs, which read the features themselves -- no launch, no `e`)
+    if (!fold_)
         gemm(kClsGemmHead, nullptr, 0, roll_in_analysis ? d_fhist_ : d_feat_, nbf_, w_in_, b_in_, d_e_, nbh_ * pi_.npb, kHidden, kOutAPlain,
              taps_);
+    const void *stage_in = fold_ ? (const void *) feat_now : (const void *) d_e_;  // the e part of every stage's layer-A input
     if (taps_ > 1 && !roll_in_analysis)  // the last taps - 1 frames of [context | call] are the next call's context
         (void) hipMemcpyAsync(fhist_last, (char *) d_feat_ + (size_t) T * feat_frame_bytes_, (size_t) (taps_ - 1) * feat_frame_bytes_,
                               hipMemcpyDeviceToDevice, stream_);
@@ -815,17 +842,17 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         const void *yprev = s ? d_y_[s - 1] : nullptr;
         const int nby = s ? nby_[s - 1] : 0;
         if (small) {
-            gru_small(yprev, nby, d_e_, d.w_ih_a, d.b_ih_a, d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_, 0, head_in_next ? &sd_[s - 1] : nullptr);
+            gru_small(yprev, nby, stage_in, d.w_ih_a, d.b_ih_a, d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_, 0, head_in_next ? &sd_[s - 1] : nullptr);
             gru_small(nullptr, 0, d_hseq_a_, d.w_ih_b, d.b_ih_b, d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_);
         } else if (small_steps) {
-            for (int t = 0; t < T; ++t) gru_small(yprev, nby, d_e_, d.w_ih_a, d.b_ih_a, d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_, t);
+            for (int t = 0; t < T; ++t) gru_small(yprev, nby, stage_in, d.w_ih_a, d.b_ih_a, d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_, t);
             for (int t = 0; t < T; ++t)
                 gru_small(nullptr, 0, d_hseq_a_, d.w_ih_b, d.b_ih_b, d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_, t);
         } else {
             if (quad && nby <= quad_nb0_max_) {
-                gru_quad(yprev, nby, d_e_, d.w_ih_a, d.b_ih_a, d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_, head_in_next ? &sd_[s - 1] : nullptr);
+                gru_quad(yprev, nby, stage_in, d.w_ih_a, d.b_ih_a, d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_, head_in_next ? &sd_[s - 1] : nullptr);
             } else {
-                gemm(kClsGemmIn, yprev, nby, d_e_, nbh_, d.w_ih_a, d.b_ih_a, d_gi_, kGateTiles, 3 * kHidden, kOutGi);
+                gemm(kClsGemmIn, yprev, nby, stage_in, nbh_, d.w_ih_a, d.b_ih_a, d_gi_, kGateTiles, 3 * kHidden, kOutGi);
                 gru(d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_);
             }
             if (quad) {
@@ -1131,6 +1158,10 @@ int64_t Engine::debug_read(int what, float *out, int64_t capacity, std::string *
     if ((what == 0 && !feat_valid_) || (what == 2 && !mask_valid_)) {
         *err = "the last call kept this intermediate on chip (one-frame calls fuse the front-end / the mask head into the STFT "
                "launches): use the developer build with its debug-taps switch";
+        return -1;
+    }
+    if (what == 4 && fold_) {
+        *err = "this configuration forms no embedding (bf16, one-frame front-end: folded into the stage-input GEMMs)";
         return -1;
     }
     if (what == 0 || what == 4) {  // features / embedding

@@ -86,6 +86,7 @@ private:
     // front-end context (front_taps > 1): features of the last front_taps - 1 frames (A-packed, one "frame" = mtiles x nbf
     // blocks), and one m-tile of the feature of a silent frame (what the context holds before a stream began)
     int taps_ = 1;
+    bool fold_ = false;  // bf16, one-frame front-end: folded into the stage-input GEMMs (no front-end launch, no embedding buffer)
     void *d_fhist_ = nullptr, *d_silent_ = nullptr;
     size_t feat_frame_bytes_ = 0;
 

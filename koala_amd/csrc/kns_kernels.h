@@ -48,12 +48,6 @@ struct AnalysisArgs {
     int B, Bpad, T, nbf, precision;
     int seg;         // frames per workgroup (a workgroup walks a time segment of its 16 streams)
     int write_spec;  // 0: the synthesis kernel rebuilds the spectrum from the PCM, nothing is stored
-    // optional (one-frame calls, bf16, one-frame front-end): the front-end GEMM e = features . W_in + b_in inside this launch --
-    // four further waves keep W_in in registers and work on the feature tile while it is still in LDS; `feat` may then be null
-    const void *front_w = nullptr;   // B-packed [18][nbf]
-    const float *front_b = nullptr;  // [18 * 16]
-    void *front_out = nullptr;       // A-packed [mtiles][9]
-    int front_valid = 0;             // columns >= front_valid are zero
     // optional (one-frame calls, front-end over several frames): `feat` is the LAST slot of a feature history of hist_slots + 1
     // frames [slot][mtiles][nbf]; before it is written the workgroup rolls its m-tile's history by one frame (slots 1 .. hist_slots
     // -> 0 .. hist_slots - 1), so that afterwards the slots are the front-end's taps, oldest first -- no copy launches

@@ -102,52 +102,13 @@ __device__ __forceinline__ float feature_log(float x) {
 
 // grid (stream tiles, time segments): a workgroup walks the frames [t0, t1) of its 16 streams, so every PCM sample is
 // read once (the previous frame stays in registers) and the per-lane constants are set up once per segment.
-// kFront (one-frame calls, bf16): waves 4..7 are the front-end GEMM -- e = features . W_in + b_in of the workgroup's m-tile, W_in
-// resident in their registers (requested at the start, there when the feature tile is), the tile read from LDS, e leaves as the
-// next layer's A operand.  Chains k-ascending from zero, bias after: what gemm_kernel<kOutAPlain> / gemm_wsr_kernel compute.
-constexpr int kFrontTiles = PBF16::NBH * PBF16::NPB;  // 18 n-tiles of 16 columns (271 -> 288)
-template <class P, bool kSpec, bool kFront>
-__global__ __launch_bounds__(kFront ? 512 : 256, kFront ? 1 : 3) void analysis_kernel(AnalysisArgs g) {
+template <class P, bool kSpec>
+__global__ __launch_bounds__(256, 3) void analysis_kernel(AnalysisArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lmean = (float *) (smem + kOffAEnd), *lscale = lmean + 272;
     typename P::elem_t *tile = (typename P::elem_t *) (smem + kOffAEnd + 2 * 272 * 4);  // nbf KiB
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (kFront && wave >= 4) {
-        typedef typename P::frag_t frag_t;
-        constexpr int NB = P::NBH;       // feature k-blocks (257 -> 288) = hidden k-blocks
-        constexpr int kPer = (kFrontTiles + 3) / 4;
-        const int gw = wave - 4, colq = lane & 15;
-        frag_t w[kPer][NB];
-        float bias[kPer];
-#pragma unroll
-        for (int q = 0; q < kPer; ++q) {  // n-tiles gw, gw + 4, ...; a slot past the last tile repeats it (same words, same values)
-            const int nt = gw + 4 * q < kFrontTiles ? gw + 4 * q : kFrontTiles - 1;
-#pragma unroll
-            for (int kb = 0; kb < NB; ++kb) w[q][kb] = ((const frag_t *) g.front_w)[((size_t) nt * NB + kb) * 64 + lane];
-            bias[q] = g.front_b[nt * 16 + colq];
-        }
-        char *etile = smem + kOffAEnd + 2 * 272 * 4 + g.nbf * 1024;  // [9] KiB, A-fragment order
-        __syncthreads();  // (tables: the STFT waves' first barrier)
-        __syncthreads();  // the feature tile is complete
-#pragma unroll
-        for (int q = 0; q < kPer; ++q) {
-            const int nt = gw + 4 * q < kFrontTiles ? gw + 4 * q : kFrontTiles - 1;
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kb = 0; kb < NB; ++kb) acc = P::mma(((const frag_t *) tile)[kb * 64 + lane], w[q][kb], acc);
-            typename P::elem_t *sc = (typename P::elem_t *) (etile + (nt / P::NPB) * 1024);
-            const bool pad = nt * 16 + colq >= g.front_valid;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                sc[P::off((lane >> 4) * 4 + i, (nt % P::NPB) * 16 + colq)] = P::cvt(pad ? 0.0f : acc[i] + bias[q]);
-        }
-        __syncthreads();  // e complete (the STFT waves' third barrier)
-        const uint4 *src = (const uint4 *) etile;
-        uint4 *dst = (uint4 *) g.front_out + (size_t) blockIdx.x * NB * 64;
-        for (int i = tid - 256; i < NB * 64; i += 256) dst[i] = src[i];
-        return;
-    }
     const int c = fft_column(lane), q = lane >> 4, row = wave * 4 + q;
     const int mt = blockIdx.x, mtiles = g.Bpad >> 4;
     const int t0 = blockIdx.y * g.seg, t1 = min(g.T, t0 + g.seg);
@@ -159,7 +120,7 @@ __global__ __launch_bounds__(kFront ? 512 : 256, kFront ? 1 : 3) void analysis_k
 
     // (one-frame calls of a several-frame front-end) this m-tile's feature history, slots 1 .. hist_slots, on its way to LDS; it
     // goes back one slot down after the first barrier, when all of it has been read
-    char *hroll = smem + kOffAEnd + 2 * 272 * 4 + (size_t) (kFront ? 2 : 1) * g.nbf * 1024;
+    char *hroll = smem + kOffAEnd + 2 * 272 * 4 + (size_t) g.nbf * 1024;
     if (g.feat_hist) {
         typedef const __attribute__((address_space(1))) void *gptr_t;
         typedef __attribute__((address_space(3))) void *lptr_t;
@@ -237,7 +198,7 @@ __global__ __launch_bounds__(kFront ? 512 : 256, kFront ? 1 : 3) void analysis_k
             tile[(256 / P::KB) * 64 * P::EPL + P::off(row, 256 % P::KB)] = P::cvt(fn);
         }
         __syncthreads();
-        if (!kFront || g.feat) {
+        {
             const uint4 *src = (const uint4 *) tile;
             uint4 *dst = (uint4 *) g.feat + ((size_t) t * mtiles + mt) * g.nbf * 64;
             for (int i = tid; i < g.nbf * 64; i += 256) dst[i] = src[i];
@@ -268,17 +229,15 @@ void launch_analysis(const AnalysisArgs &a, hipStream_t s) {
         hipLaunchKernelGGL(kernel, grid, dim3(threads), bytes, s, a);
     };
     if (a.precision == kBf16) {
-        if (a.front_w && a.T == 1 && a.write_spec && !a.feat_hist)  // the front-end GEMM inside (one frame: one loop iteration, three barriers)
-            go(analysis_kernel<PBF16, true, true>, 512, lds + PBF16::NBH * 1024);
-        else if (a.write_spec)
-            go(analysis_kernel<PBF16, true, false>, 256, lds);
+        if (a.write_spec)
+            go(analysis_kernel<PBF16, true>, 256, lds);
         else
-            go(analysis_kernel<PBF16, false, false>, 256, lds);
+            go(analysis_kernel<PBF16, false>, 256, lds);
     } else {
         if (a.write_spec)
-            go(analysis_kernel<PF32, true, false>, 256, lds);
+            go(analysis_kernel<PF32, true>, 256, lds);
         else
-            go(analysis_kernel<PF32, false, false>, 256, lds);
+            go(analysis_kernel<PF32, false>, 256, lds);
     }
 }
 

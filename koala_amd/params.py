@@ -55,7 +55,10 @@ def write_params(path: str, tensors: Dict[str, np.ndarray]) -> None:
     front_taps = int(np.asarray(tensors["w_in"]).shape[0]) // BINS
     with open(tmp, "wb") as f:
         f.write(MAGIC)
-        f.write(struct.pack("<14I", 1, N_FFT, HOP, BINS, HIDDEN, STAGES, *HEADS, DELAY, front_taps if front_taps > 1 else 0, 0, 0))
+        # word 12 (oracle-only, tools/pv_hypotheses.py): pre-activations re-quantised to int16 with that many fractional bits,
+        # saturating -- an emulation of a fixed-point engine's hand-over between GEMMs; 0 = off (every engine-runnable model)
+        act_q = int(np.asarray(tensors.get("__act_q__", 0)))
+        f.write(struct.pack("<14I", 1, N_FFT, HOP, BINS, HIDDEN, STAGES, *HEADS, DELAY, front_taps if front_taps > 1 else 0, act_q, 0))
         for name, shape in tensor_order(front_taps):
             a = np.ascontiguousarray(tensors[name], dtype="<f4")
             if a.shape != shape:

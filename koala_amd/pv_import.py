@@ -69,6 +69,16 @@ class Hypothesis(NamedTuple):
     y_first: bool = True         # stage-input rows ordered [y_prev ; e] (False: [e ; y_prev])
     head_shift: int = 7
     head_bias_shift: int = 5
+    # round 4: the per-stage int16 behind each head block (3056, 1013, 1379, 1713) as a fixed-point multiplier c = value / 2^tail_q
+    # (the reference ships exactly one "elementwise with int16 scalar" kernel, SURVEY.md 2.2 `taabe194`):
+    #   'none'      not used (rounds 2-3)
+    #   'preact'    scales the head's pre-activation: y_s = sigmoid(c (h W + b))
+    #   'out'       scales the head's output where the next stage consumes it: the y rows of stage s + 1's W_ih (the last stage's, the
+    #               mask, cannot be folded into KNS1 and is left alone)
+    #   'embed'     scales the embedding share of the NEXT stage's input (the e rows of stage s + 1's W_ih)
+    tail_mode: str = 'none'
+    tail_q: int = 12
+    act_q: int = 0               # oracle-only: GEMM outputs re-quantised to saturating int16 with act_q fractional bits (0 = off)
 
 
 def _block(b: bytes, o: int, rows: int, cols: int) -> Block:
@@ -138,6 +148,18 @@ def to_kns1(model: PvModel, hyp: Hypothesis = Hypothesis()) -> Dict[str, np.ndar
         blk = next(it)
         t['s%d.w_head' % s][:] = blk.weights.astype(np.float64) * 2.0 ** -hyp.head_shift
         t['s%d.b_head' % s][:] = blk.trailer.astype(np.float64) * 2.0 ** -hyp.head_bias_shift
+    if hyp.tail_mode != 'none':
+        for s in range(params.STAGES):
+            c = float(model.stage_tail[s]) / 2.0 ** hyp.tail_q
+            d_out = params.HEADS[s]
+            if hyp.tail_mode == 'preact':
+                t['s%d.w_head' % s] *= c
+                t['s%d.b_head' % s] *= c
+            elif s + 1 < params.STAGES:  # (the y rows come first in KNS1's stage input [y_prev ; e])
+                rows = slice(0, d_out) if hyp.tail_mode == 'out' else slice(d_out, d_out + params.HIDDEN)
+                t['s%d.w_ih_a' % (s + 1)][rows] *= c
+    if hyp.act_q:
+        t['__act_q__'] = np.int32(hyp.act_q)
     return t
 
 

@@ -128,11 +128,16 @@ typedef struct {
     float *w_head, *b_head;                   /* [H][d_out] */
     /* bf16 mode: [H + 2][3H] = the (scaled, bf16-rounded) W_hh with the scaled b_hh appended as two bf16 rows hi, lo (malloc'd) */
     float *w_hh_a_aug, *w_hh_b_aug;
+    /* bf16 mode, folded front-end: [d_in + 257][3H] weights over [y_prev ; features] and their bias (malloc'd) */
+    float *w_ih_a_fold, *b_ih_a_fold;
 } kns_stage_t;
 
 struct kns_params {
     int precision;
     int front_taps; /* feature frames the front-end sees (1 = KNS-v1; > 1: oracle-only extension, see kns_oracle.h) */
+    int fold;       /* bf16 mode, one-frame front-end: the front-end is folded into the stage-input GEMMs (see fold_front) */
+    int act_q;      /* oracle-only (header word 12, tools/pv_hypotheses.py): > 0 = every GEMM output is re-quantised to a saturating
+                     * int16 with act_q fractional bits before it is used (a fixed-point engine's hand-over); 0 = off */
     int head[KNS_STAGES];
     int delay;
     float *blob;
@@ -182,6 +187,35 @@ static float *augment_whh(const float *w_hh /* scaled, rounded */, const float *
     return a;
 }
 
+/* bf16 mode: the front-end is linear and nothing but the stage-input GEMMs consumes its output,
+ * so it is FOLDED into them: with W_e the embedding rows of a stage's (gate-scaled, unrounded) W_ih,
+ *     Wc[k][n] = sum_j w_in[k][j] W_e[j][n]   (j ascending, fmaf from 0),   b'[n] = b_ih[n] + sum_j b_in[j] W_e[j][n]   (likewise)
+ * in fp32, THEN rounded to bf16: stage input [y_prev ; features], K = d_in + 257; the embedding is never formed (one GEMM launch,
+ * one bf16 rounding and 2 x 257 x 271 flop per frame less).  The engine packs the same matrices (kns_engine.cpp, fold_front). */
+static void fold_front(const float *w_in, const float *b_in, const float *w_ih /* [d_in + H][3H] scaled, unrounded */,
+                       const float *b_ih /* scaled */, int d_in, float **w_out, float **b_out) {
+    float *w = (float *) malloc(sizeof(float) * (size_t) (d_in + KNS_BINS) * KNS_G3);
+    float *b = (float *) malloc(sizeof(float) * KNS_G3);
+    memcpy(w, w_ih, sizeof(float) * (size_t) d_in * KNS_G3);
+    const float *we = w_ih + (size_t) d_in * KNS_G3;
+    for (int k = 0; k < KNS_BINS; ++k) {
+        float *row = w + (size_t) (d_in + k) * KNS_G3;
+        for (int n = 0; n < KNS_G3; ++n) row[n] = 0.0f;
+        for (int j = 0; j < KNS_H; ++j) {
+            const float a = w_in[(size_t) k * KNS_H + j];
+            const float *wr = we + (size_t) j * KNS_G3;
+            for (int n = 0; n < KNS_G3; ++n) row[n] = fmaf(a, wr[n], row[n]);
+        }
+    }
+    for (int n = 0; n < KNS_G3; ++n) b[n] = 0.0f;
+    for (int j = 0; j < KNS_H; ++j)
+        for (int n = 0; n < KNS_G3; ++n) b[n] = fmaf(b_in[j], we[(size_t) j * KNS_G3 + n], b[n]);
+    for (int n = 0; n < KNS_G3; ++n) b[n] = b_ih[n] + b[n];
+    round_weights(w, (size_t) (d_in + KNS_BINS) * KNS_G3);
+    *w_out = w;
+    *b_out = b;
+}
+
 int kns_params_load(const char *path, int precision, kns_params_t **out) {
     FILE *f = fopen(path, "rb");
     if (!f) return -1;
@@ -200,6 +234,7 @@ int kns_params_load(const char *path, int precision, kns_params_t **out) {
     p->precision = precision;
     p->delay = (int) hdr[10];
     p->front_taps = hdr[11] > 1 && hdr[11] <= (uint32_t) KNS_MAX_FRONT_TAPS ? (int) hdr[11] : 1;
+    p->act_q = hdr[12] <= 15 ? (int) hdr[12] : 0;
     if (hdr[11] > (uint32_t) KNS_MAX_FRONT_TAPS) { /* (compared as the unsigned word it is) */
         fclose(f);
         free(p);
@@ -235,14 +270,29 @@ int kns_params_load(const char *path, int precision, kns_params_t **out) {
     } while (0)
     TAKE(p->mean, KNS_BINS, 0);
     TAKE(p->scale, KNS_BINS, 0);
+    p->fold = bf && p->front_taps == 1 && !getenv("KNS_ORACLE_NO_FOLD");
+    float *w_in_raw = NULL;
+    if (p->fold) {
+        w_in_raw = (float *) malloc(sizeof(float) * (size_t) KNS_BINS * KNS_H);
+        memcpy(w_in_raw, q, sizeof(float) * (size_t) KNS_BINS * KNS_H);
+    }
     TAKE(p->w_in, p->front_taps * KNS_BINS * KNS_H, 1);
     TAKE(p->b_in, KNS_H, 0);
     for (int s = 0; s < KNS_STAGES; ++s) {
         kns_stage_t *st = &p->st[s];
         st->d_in = s ? p->head[s - 1] : 0;
         st->d_out = p->head[s];
-        TAKE_GRU(st->w_ih_a, st->d_in + KNS_H, 1);
-        TAKE_GRU(st->b_ih_a, 1, 0);
+        if (p->fold) { /* from the scaled but unrounded matrix, before TAKE rounds it in place */
+            scale_gates(q, (size_t) (st->d_in + KNS_H));
+            float *bq = q + (size_t) (st->d_in + KNS_H) * KNS_G3;
+            scale_gates(bq, 1);
+            fold_front(w_in_raw, p->b_in, q, bq, st->d_in, &st->w_ih_a_fold, &st->b_ih_a_fold);
+            TAKE(st->w_ih_a, (size_t) (st->d_in + KNS_H) * KNS_G3, 1);
+            TAKE(st->b_ih_a, KNS_G3, 0);
+        } else {
+            TAKE_GRU(st->w_ih_a, st->d_in + KNS_H, 1);
+            TAKE_GRU(st->b_ih_a, 1, 0);
+        }
         TAKE_GRU(st->w_hh_a, KNS_H, 1);
         TAKE_GRU(st->b_hh_a, 1, 0);
         TAKE_GRU(st->w_ih_b, KNS_H, 1);
@@ -257,6 +307,7 @@ int kns_params_load(const char *path, int precision, kns_params_t **out) {
         }
     }
 #undef TAKE_GRU
+    free(w_in_raw);
 #undef TAKE
     tables_init(p);
     *out = p;
@@ -268,6 +319,8 @@ void kns_params_free(kns_params_t *p) {
     for (int s = 0; s < KNS_STAGES; ++s) {
         free(p->st[s].w_hh_a_aug);
         free(p->st[s].w_hh_b_aug);
+        free(p->st[s].w_ih_a_fold);
+        free(p->st[s].b_ih_a_fold);
     }
     free(p->blob);
     free(p);
@@ -630,9 +683,16 @@ static void gemm_block(int nb, const float *x, int ldx, int K, const float *w, i
     gemm_block_b(nb, x, ldx, K, w, N, bias, acc, lda, round_x, 0);
 }
 
+/* oracle-only fixed-point emulation: v -> clamp(round(v 2^q), int16) 2^-q */
+static void requant(float *v, size_t n, int q) {
+    if (q <= 0) return;
+    const float s = (float) (1 << q), inv = 1.0f / s;
+    for (size_t i = 0; i < n; ++i) v[i] = fminf(fmaxf(rintf(v[i] * s), -32768.0f), 32767.0f) * inv;
+}
+
 /* one GRU layer step for a block of streams:  x [nb][K] -> h (in/out) [nb] pointers */
 static void gru_block(int nb, const float *x, int ldx, int K, const float *w_ih, const float *b_ih, const float *w_hh,
-                      const float *b_hh, const float *w_hh_aug, float **h, int bf, float *gi, float *gh, float *hx) {
+                      const float *b_hh, const float *w_hh_aug, float **h, int bf, float *gi, float *gh, float *hx, int act_q) {
     gemm_block(nb, x, ldx, K, w_ih, KNS_G3, b_ih, gi, KNS_G3, bf);
     if (bf) { /* gh = [h ; 1 ; 1] . [W_hh ; b_hi ; b_lo]: the bias is the last two links of the chain */
         static const float zero[KNS_G3];
@@ -645,6 +705,59 @@ static void gru_block(int nb, const float *x, int ldx, int K, const float *w_ih,
     } else {
         for (int s = 0; s < nb; ++s) memcpy(hx + (size_t) s * KNS_H, h[s], sizeof(float) * KNS_H);
         gemm_block_b(nb, hx, KNS_H, KNS_H, w_hh, KNS_G3, b_hh, gh, KNS_G3, 0, 0);
+    }
+    requant(gi, (size_t) nb * KNS_G3, act_q);
+    requant(gh, (size_t) nb * KNS_G3, act_q);
+    /* experiment (KNS_ORACLE_GI_PAYLOAD, bf16 mode): the input-side pre-activations travel in 8 bits instead of
+     * fp16 -- "int8": four streams' values of one (unit, gate) share a power-of-two scale (what one lane of a C fragment holds), 7-bit
+     * magnitude; "e4m3": fp8 with 3 mantissa bits.  Only the mask RMS against the fp32 path is read off this (profiles/r04_gi_payload.txt). */
+    static int payload = -1;
+    if (payload < 0) {
+        const char *e = getenv("KNS_ORACLE_GI_PAYLOAD");
+        payload = !e ? 0 : !strcmp(e, "int8") ? 1 : !strcmp(e, "e4m3") ? 2 : !strcmp(e, "int8tile") ? 3 : 0;
+    }
+    if (bf && payload == 1) {
+        for (int s0 = 0; s0 < nb; s0 += 4)
+            for (int c = 0; c < KNS_G3; ++c) {
+                float mx = 0.0f;
+                for (int s = s0; s < nb && s < s0 + 4; ++s) mx = fmaxf(mx, fabsf(gi[(size_t) s * KNS_G3 + c]));
+                if (mx == 0.0f) continue;
+                int ex;
+                (void) frexpf(mx / 127.0f, &ex); /* mx / 127 = f 2^ex, f in [0.5, 1): scale 2^ex >= mx / 127 */
+                const float sc = ldexpf(1.0f, ex);
+                for (int s = s0; s < nb && s < s0 + 4; ++s) {
+                    float *v = &gi[(size_t) s * KNS_G3 + c];
+                    *v = fminf(fmaxf(rintf(*v / sc), -127.0f), 127.0f) * sc;
+                }
+            }
+    } else if (bf && payload == 3) { /* one power-of-two scale per 16 streams x 16 units of a gate (a whole C fragment) */
+        for (int s0 = 0; s0 < nb; s0 += 16)
+            for (int gate = 0; gate < 3; ++gate)
+                for (int u0 = 0; u0 < KNS_H; u0 += 16) {
+                    const int cbeg = gate * KNS_H + u0, cend = gate * KNS_H + (u0 + 16 < KNS_H ? u0 + 16 : KNS_H);
+                    float mx = 0.0f;
+                    for (int s = s0; s < nb && s < s0 + 16; ++s)
+                        for (int c = cbeg; c < cend; ++c) mx = fmaxf(mx, fabsf(gi[(size_t) s * KNS_G3 + c]));
+                    if (mx == 0.0f) continue;
+                    int ex;
+                    (void) frexpf(mx / 127.0f, &ex);
+                    const float sc = ldexpf(1.0f, ex);
+                    for (int s = s0; s < nb && s < s0 + 16; ++s)
+                        for (int c = cbeg; c < cend; ++c) {
+                            float *v = &gi[(size_t) s * KNS_G3 + c];
+                            *v = fminf(fmaxf(rintf(*v / sc), -127.0f), 127.0f) * sc;
+                        }
+                }
+    } else if (bf && payload == 2) {
+        for (size_t i = 0; i < (size_t) nb * KNS_G3; ++i) { /* e4m3: 3 mantissa bits, saturating at 448, subnormals below 2^-6 */
+            float v = gi[i], a = fabsf(v);
+            if (a > 448.0f) a = 448.0f;
+            int ex;
+            (void) frexpf(a, &ex);
+            if (ex < -5) ex = -5;
+            const float q = ldexpf(1.0f, ex - 4);
+            gi[i] = copysignf(rintf(a / q) * q, v);
+        }
     }
     for (int s = 0; s < nb; ++s) {
         float *gis = gi + (size_t) s * KNS_G3, *ghs = gh + (size_t) s * KNS_G3;
@@ -695,7 +808,9 @@ static void frame_block(const kns_params_t *p, int nb, kns_stream_t **st, const 
         analysis(p, st[s]->hist, pcm[s], w->spec[s], w->feat[s]);
         memcpy(st[s]->hist, pcm[s], sizeof(int16_t) * KNS_FRAME);
     }
-    if (p->front_taps == 1) {
+    if (p->fold) {
+        memset(w->e, 0, sizeof(float) * (size_t) nb * KNS_H); /* no embedding: the stages read the features (fold_front) */
+    } else if (p->front_taps == 1) {
         gemm_block(nb, &w->feat[0][0], KNS_BINS, KNS_BINS, p->w_in, KNS_H, p->b_in, &w->e[0][0], KNS_H, bf);
     } else { /* oracle-only extension: the front-end sees the last `front_taps` feature frames, oldest first */
         const int ht = p->front_taps - 1;
@@ -717,6 +832,7 @@ static void frame_block(const kns_params_t *p, int nb, kns_stream_t **st, const 
         gemm_block(nb, &w->fstack[0][0], KNS_MAX_FRONT_TAPS * KNS_BINS, p->front_taps * KNS_BINS, p->w_in, KNS_H, p->b_in,
                    &w->e[0][0], KNS_H, bf);
     }
+    requant(&w->e[0][0], (size_t) nb * KNS_H, p->act_q);
     if (bf)
         for (int s = 0; s < nb; ++s)
             for (int j = 0; j < KNS_H; ++j) w->e[s][j] = kns_round_bf16(w->e[s][j]);
@@ -724,20 +840,23 @@ static void frame_block(const kns_params_t *p, int nb, kns_stream_t **st, const 
     int tap_off = 0;
     for (int sg = 0; sg < KNS_STAGES; ++sg) {
         const kns_stage_t *g = &p->st[sg];
-        const int K = g->d_in + KNS_H;
+        const int K = g->d_in + (p->fold ? KNS_BINS : KNS_H);
         for (int s = 0; s < nb; ++s) {
             memcpy(&w->xin[s][0], &w->y[s][0], sizeof(float) * (size_t) g->d_in);
-            memcpy(&w->xin[s][g->d_in], &w->e[s][0], sizeof(float) * KNS_H);
+            if (p->fold)
+                memcpy(&w->xin[s][g->d_in], &w->feat[s][0], sizeof(float) * KNS_BINS);
+            else
+                memcpy(&w->xin[s][g->d_in], &w->e[s][0], sizeof(float) * KNS_H);
             hp[s] = st[s]->h[2 * sg];
         }
-        gru_block(nb, &w->xin[0][0], KNS_H + 64, K, g->w_ih_a, g->b_ih_a, g->w_hh_a, g->b_hh_a, g->w_hh_a_aug, hp, bf, w->gi,
-                  w->gh, w->hx);
+        gru_block(nb, &w->xin[0][0], KNS_H + 64, K, p->fold ? g->w_ih_a_fold : g->w_ih_a, p->fold ? g->b_ih_a_fold : g->b_ih_a,
+                  g->w_hh_a, g->b_hh_a, g->w_hh_a_aug, hp, bf, w->gi, w->gh, w->hx, p->act_q);
         /* layer B consumes layer A's new hidden state */
         for (int s = 0; s < nb; ++s) {
             memcpy(w->xa + (size_t) s * KNS_H, st[s]->h[2 * sg], sizeof(float) * KNS_H);
             hp[s] = st[s]->h[2 * sg + 1];
         }
-        gru_block(nb, w->xa, KNS_H, KNS_H, g->w_ih_b, g->b_ih_b, g->w_hh_b, g->b_hh_b, g->w_hh_b_aug, hp, bf, w->gi, w->gh, w->hx);
+        gru_block(nb, w->xa, KNS_H, KNS_H, g->w_ih_b, g->b_ih_b, g->w_hh_b, g->b_hh_b, g->w_hh_b_aug, hp, bf, w->gi, w->gh, w->hx, p->act_q);
         for (int s = 0; s < nb; ++s) memcpy(w->hx + (size_t) s * KNS_H, st[s]->h[2 * sg + 1], sizeof(float) * KNS_H);
         gemm_block(nb, w->hx, KNS_H, KNS_H, g->w_head, g->d_out, g->b_head, &w->y[0][0], KNS_BINS, bf);
         for (int s = 0; s < nb; ++s)

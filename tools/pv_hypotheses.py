@@ -6,7 +6,7 @@ Scores import hypotheses for the reference's model file (koala_amd.pv_import.Hyp
 order, stage-input row order, feature-table formats, which of the front-end's five context frames a one-frame front-end
 keeps) by the one behavioural contract the reference publishes: the acceptance envelope of
 binding/python/test_koala.py:71-114 on test.wav, noise.wav and their mix, evaluated with the CPU oracle.
-Writes profiles/r02_pv_import_search.json: how many hypotheses were tried, the distribution of the scores and the best
+Writes profiles/r04_pv_import_search.json (round 2: r02_..., its space is in the history): how many hypotheses were tried, the distribution of the scores and the best
 ones with all three deviations.  A score below 0.02 would mean "this reading of the bytes behaves like a noise suppressor
 on the reference's own fixtures"; whatever comes out is recorded as measured.
 """
@@ -25,10 +25,15 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 PV = '/root/reference/lib/common/koala_params.pv'
 
-SPACE = dict(weight_shift=[5, 6, 7, 8, 9], bias_shift=[3, 4, 5, 6, 7], front_shift=[5, 6, 7, 8, 9], front_bias_shift=[3, 4, 5, 6, 7],
-             front_tap=[-1, 0, 4, 5, 5, 5, 6, 6, 6], mean_div=[256.0, 512.0, 1024.0], scale_div=[2048.0, 4096.0, 8192.0],
+# Round 4: shift ranges where round 3's byte statistics (tools/pv_prune.py) put unsaturated gates, the five-frame front-end always
+# on, and the two structural hypotheses of VERDICT r3 item 8: the per-stage int16 as a fixed-point multiplier (tail_mode / tail_q) and
+# saturating int16 re-quantisation of every GEMM output (act_q, emulated by the oracle only)
+SPACE = dict(weight_shift=[6, 7, 8, 9, 10, 11], bias_shift=[3, 4, 5, 6, 7], front_shift=[9, 10, 11, 12, 13], front_bias_shift=[3, 4, 5, 6, 7],
+             front_tap=[5, 6], mean_div=[256.0, 512.0, 1024.0], scale_div=[2048.0, 4096.0, 8192.0],
              log2_features=[False, True], gate_order=[''.join(p) for p in itertools.permutations('rzn')], y_first=[True, False],
-             head_shift=[5, 6, 7, 8], head_bias_shift=[3, 4, 5, 6])
+             head_shift=[5, 6, 7, 8, 9, 10], head_bias_shift=[3, 4, 5, 6],
+             tail_mode=['none', 'preact', 'preact', 'out', 'out', 'embed', 'embed'], tail_q=[10, 11, 12],
+             act_q=[0, 0, 8, 10, 12])
 
 
 def rms(x):
@@ -58,6 +63,10 @@ def evaluate(h):
     return h, dev
 
 
+def sc(d):
+    return max(d['speech'], d['noise'], d['mixed'])
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1600
     rnd = random.Random(20260928)
@@ -67,8 +76,6 @@ def main():
     with mp.Pool(min(8, os.cpu_count() or 1)) as pool:
         results = pool.map(evaluate, hyps, chunksize=8)
         # second phase: coordinate descent (one field at a time, all its values) from the best random hypotheses
-        def sc(d):
-            return max(d['speech'], d['noise'], d['mixed'])
         ranked = sorted(results, key=lambda r: sc(r[1]))
         descents = []
         for start, _ in ranked[:4]:
@@ -104,9 +111,19 @@ def main():
         'coordinate_descent_from_the_best_four': descents,
         'best_suppressor_like': [{'hypothesis': h, 'metrics': d} for h, d in sorted(useful, key=lambda r: r[1]['noise_gain_db'])[:5]],
     }
-    path = os.path.join(ROOT, 'profiles', 'r02_pv_import_search.json')
+    def best_by(field):
+        groups = {}
+        for h, d in results:
+            groups.setdefault(str(h.get(field, getattr(pv_defaults, field))), []).append(sc(d))
+        return {k: {'tried': len(v), 'best': float(min(v)), 'median': float(np.median(v))} for k, v in sorted(groups.items())}
+    from koala_amd import pv_import as _pvi
+    pv_defaults = _pvi.Hypothesis()
+    out['by_tail_mode'] = best_by('tail_mode')
+    out['by_tail_q'] = best_by('tail_q')
+    out['by_act_q'] = best_by('act_q')
+    path = os.path.join(ROOT, 'profiles', 'r04_pv_import_search.json')
     json.dump(out, open(path, 'w'), indent=1)
-    print(json.dumps({k: out[k] for k in ('hypotheses_tried', 'score_quantiles', 'passing', 'suppressor_like')}, indent=1))
+    print(json.dumps({k: out[k] for k in ('hypotheses_tried', 'score_quantiles', 'passing', 'suppressor_like', 'by_tail_mode', 'by_tail_q', 'by_act_q')}, indent=1))
     for e in out['best'][:3]:
         print(e)
 
