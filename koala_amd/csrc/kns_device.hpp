@@ -330,9 +330,13 @@ __device__ __forceinline__ void buf_store_f32x4(__amdgpu_buffer_rsrc_t r, unsign
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
 }
+// `gi` is written once and read once (428 MB per layer at the bench shape, more than the 256 MB memory-side cache): both sides
+// mark it non-temporal (aux = 2), which leaves the cache to the hidden sequences the next kernels re-read -- +0.5 % on the step, the
+// narrow heads 42 -> 39 us (round 4; either side alone measured -0.2 ... -0.4 %)
+constexpr int kGiStreamAux = 2;
 __device__ __forceinline__ void buf_store_gi(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f16x4 v) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, kGiStreamAux);
 }
 
 // a * b + c of the bf16 configuration's gate arithmetic: fused (what the spec and the oracle write: n = tanh(fma(r, gh_n,

@@ -348,7 +348,7 @@ __device__ __forceinline__ void r8_tile_mma(f32x4 (&acc)[3], const bf16x8 *ha, c
 }
 
 __device__ __forceinline__ f16x4 buf_load_gi(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    return __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, kGiStreamAux));
 }
 
 __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs g) {
