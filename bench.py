@@ -310,9 +310,15 @@ def extra_points(args, torch, np, koala_amd, model, kb, x, dx, dy, base, local_r
         b = torch.empty_like(a)
         n = 60 if T1 > 1 else 300
         dt = time_steps(lambda: k1.process_device(T1, a.data_ptr(), b.data_ptr()), sync, n, 10)
+        fps1 = 256 * T1 * n / dt
+        tflops = fps1 * 2.0 * (MAC_GEMM_IN + MAC_GRU + MAC_HEAD) / 1e12
         out['config1_fp32_b256_T%d' % T1] = {
             'workload': 'BASELINE configs[1]: 256 streams x %d frame(s) per call, fp32 mask net, device-resident' % T1,
-            'frames_per_s': round(256 * T1 * n / dt, 1), 'ms_per_call': round(dt / n * 1e3, 4)}
+            'frames_per_s': round(fps1, 1), 'ms_per_call': round(dt / n * 1e3, 4),
+            # the whole mask network against the fp32 matrix peak: the fp32 configuration is the bit-exact correctness path (fp32 =
+            # oracle, value for value), launch-per-frame at this size (profiles/r04_fp32_persist.txt)
+            'roofline': {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': MFMA_PEAK_TFLOPS['fp32'], 'unit': 'TFLOP/s',
+                         'frac': round(tflops / MFMA_PEAK_TFLOPS['fp32'], 4), 'flop_per_stream_frame': 2 * (MAC_GEMM_IN + MAC_GRU + MAC_HEAD)}}
         k1.delete()
 
     # -- BASELINE configs[4]: one stream, one frame per pv_koala_process call (hipGraph replay, host buffers)

@@ -15,7 +15,7 @@ HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not available')
-@pytest.mark.parametrize('src', ['kns_stft.hip', 'kns_gemm.hip', 'kns_gru.hip'])
+@pytest.mark.parametrize('src', ['kns_stft.hip', 'kns_gemm.hip', 'kns_gru.hip', 'kns_gruq.hip'])
 def test_no_store_data_hazard_and_no_spills(src, tmp_path):
     import isa_scan
     out = tmp_path / (src + '.s')
