@@ -304,16 +304,25 @@ void launch_gru_small(const GruSmallArgs &a, hipStream_t s) {
 
 // ---- 8-wave form of the resident recurrent kernel.  Measured on MI355X: a single wave per SIMD executes its MFMAs and
 // its gate VALU one after the other (a unit tile costs 432 + ~650 cycles), while two waves on one SIMD overlap them.
-// Eight waves of <= 256 registers hold the 459 KiB of W_hh as: wave w owns unit tiles w and w + 8 (wave 0 also tile 16);
-// tile w entirely in VGPRs (27 fragments), the first 14 fragments of tile w + 8 in VGPRs and its last 13 in LDS, tile 16
-// in LDS: 328 KiB of registers + 131 KiB of LDS.  A fragments are re-read from LDS per k-block.
+// Eight waves of <= 256 registers hold the 459 KiB of W_hh as: wave w owns unit tiles w and w + 8; 41 of its 54 fragments in VGPRs
+// (round 4: the first 14 of tile w and all 27 of tile w + 8), 13 in LDS, tile 16 in LDS: 328 KiB of registers + 131 KiB of LDS.
+// A fragments are re-read from LDS per k-block.
 constexpr int kR8Waves = 8;
 #ifndef R8C_Q
 #define R8C_Q 3
 #endif
-constexpr int kR8RegFrags1 = 14;                      // fragments of the second tile kept in registers
-constexpr int kR8LdsFrags1 = 27 - kR8RegFrags1;       // ... and in LDS
-constexpr int kR8Lds = 2 * PBF16::NBH * 1024 + kR8Waves * kR8LdsFrags1 * 1024 + 27 * 1024;
+// 41 of a wave's 54 fragments fit its registers; 13 live in LDS and go through a 3-deep register queue in their tile's MFMA loop.
+// Which tile carries them (R8_REG0 = register-resident fragments of the FIRST tile), A/B through bench.py on one box, us per launch:
+// 27 (rounds 1-3: the second tile carries all 13) 155.3 | 23: 160.2 | 20 (even split) 157.4 | 17: 155.8 | 14 (the first tile carries
+// all 13) 154.0.  The stamps' reading that the second MFMA window is bound by the LDS pipe (8 waves x 31 reads) did not hold: an
+// even split is slower, not faster; the first window, where all eight waves start together behind the barrier, absorbs the queue best.
+#ifndef R8_REG0
+#define R8_REG0 14
+#endif
+constexpr int kR8RegFrags0 = R8_REG0;                  // fragments of the first tile kept in registers ...
+constexpr int kR8RegFrags1 = 41 - R8_REG0;             // ... and of the second
+constexpr int kR8LdsFrags0 = 27 - kR8RegFrags0, kR8LdsFrags1 = 27 - kR8RegFrags1;  // the rest, in LDS (13 per wave in all)
+constexpr int kR8Lds = 2 * PBF16::NBH * 1024 + kR8Waves * (kR8LdsFrags0 + kR8LdsFrags1) * 1024 + 27 * 1024;
 
 // MFMAs of one unit tile whose fragments [first_lds, 27) live in LDS at wl[(i - first_lds)] (i = k_block * 3 + gate) and
 // the rest in wreg[i]; LDS fragments go through a kQ-deep register queue
@@ -357,8 +366,8 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     constexpr int NBH = P::NBH;
     __shared__ __attribute__((aligned(16))) char smem[kR8Lds + 3 * 1024 + 16];
     char *hbuf0 = smem, *hbuf1 = smem + NBH * 1024;
-    frag_t *wl1 = (frag_t *) (smem + 2 * NBH * 1024);                                   // [8 waves][13][64]
-    frag_t *wl16 = (frag_t *) (smem + 2 * NBH * 1024 + kR8Waves * kR8LdsFrags1 * 1024);  // [27][64], i = blk * 3 + gate
+    frag_t *wl1 = (frag_t *) (smem + 2 * NBH * 1024);                                   // [8 waves][13][64]: first tile's, then second tile's
+    frag_t *wl16 = (frag_t *) (smem + 2 * NBH * 1024 + kR8Waves * (kR8LdsFrags0 + kR8LdsFrags1) * 1024);  // [27][64], i = blk * 3 + gate
     f32x4 *acc16 = (f32x4 *) (smem + kR8Lds);  // [3 gates][64 lanes]: unit tile 16's accumulators, handed across waves
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -385,7 +394,11 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     // fragments that live in LDS go there directly (global -> LDS, a lane's 16 bytes at the wave-uniform address + 16 lane).
     typedef const __attribute__((address_space(1))) void *gptr_t;
     typedef __attribute__((address_space(3))) void *lptr_t;
-    frag_t *wl1w = wl1 + wave * kR8LdsFrags1 * 64;
+    frag_t *wl0w = wl1 + wave * (kR8LdsFrags0 + kR8LdsFrags1) * 64, *wl1w = wl0w + kR8LdsFrags0 * 64;
+#pragma unroll
+    for (int i = kR8RegFrags0; i < 27; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t) (whh + ((size_t) (u0 * 3 + i % 3) * NBH + i / 3) * 64 + lane),
+                                         (lptr_t) (wl0w + (i - kR8RegFrags0) * 64), 16, 0, 0);
 #pragma unroll
     for (int i = kR8RegFrags1; i < 27; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t) (whh + ((size_t) (u1 * 3 + i % 3) * NBH + i / 3) * 64 + lane),
@@ -393,9 +406,9 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     for (int i = wave; i < 27; i += kR8Waves)
         __builtin_amdgcn_global_load_lds((gptr_t) (whh + ((size_t) (u2 * 3 + i % 3) * NBH + i / 3) * 64 + lane),
                                          (lptr_t) (wl16 + i * 64), 16, 0, 0);
-    frag_t w0[27], w1[kR8RegFrags1];
+    frag_t w0[kR8RegFrags0], w1[kR8RegFrags1];
 #pragma unroll
-    for (int i = 0; i < 27; ++i) w0[i] = whh[((size_t) (u0 * 3 + i % 3) * NBH + i / 3) * 64 + lane];
+    for (int i = 0; i < kR8RegFrags0; ++i) w0[i] = whh[((size_t) (u0 * 3 + i % 3) * NBH + i / 3) * 64 + lane];
 #pragma unroll
     for (int i = 0; i < kR8RegFrags1; ++i) w1[i] = whh[((size_t) (u1 * 3 + i % 3) * NBH + i / 3) * 64 + lane];
     f32x4 hreg[2];
@@ -497,7 +510,7 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
         KNS_STAMP(1);
         f32x4 acc[3];
         acc_init(acc, u0);
-        r8_tile_mma<27, 1, 27>(acc, ha, w0, wl16, lane);
+        r8_tile_mma<kR8RegFrags0, R8C_Q, kR8RegFrags0>(acc, ha, w0, wl0w, lane);
         KNS_STAMP(2);
         gates(0, acc);
         KNS_STAMP(3);
