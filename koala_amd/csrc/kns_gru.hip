@@ -382,9 +382,15 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     // gate each, the full k chain in one accumulator, so the arithmetic is unchanged) through their second tile's k loop
     // as a fourth accumulator, the accumulators cross LDS behind a step-count flag, and waves 0..3 each do the gate math of
     // one of the four rows a lane owns.  One barrier per step.
-    const int g16 = wave - 1;         // gate whose tile-16 MFMAs this wave computes (waves 1..3)
-    const bool c16 = wave >= 1 && wave <= 3;
-    const bool q16 = wave < 4;        // this wave finishes row (lane >> 4) * 4 + wave of tile 16
+#ifndef R8_CHAIN0
+#define R8_CHAIN0 1
+#endif
+#ifndef R8_ROW0
+#define R8_ROW0 0
+#endif
+    const int g16 = wave - R8_CHAIN0;  // gate whose tile-16 MFMAs this wave computes (waves R8_CHAIN0 .. R8_CHAIN0 + 2)
+    const bool c16 = wave >= R8_CHAIN0 && wave <= R8_CHAIN0 + 2;
+    const bool q16 = wave >= R8_ROW0 && wave < R8_ROW0 + 4;  // this wave finishes row (lane >> 4) * 4 + (wave - R8_ROW0) of tile 16
     // flags accessed with explicit ds instructions: a volatile access or a workgroup fence would make hipcc drain every
     // outstanding global load of the wave (s_waitcnt vmcnt(0)) first
     const unsigned flag16 = (unsigned) (uintptr_t) (smem + kR8Lds + 3 * 1024);  // [3 gates]: step count of acc16's content
@@ -414,7 +420,7 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     f32x4 hreg[2];
     hreg[0] = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u0) * 64 + lane];
     hreg[1] = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u1) * 64 + lane];
-    const int e16 = q16 ? wave : 0;  // element of the f32x4 this wave owns in tile 16
+    const int e16 = q16 ? wave - R8_ROW0 : 0;  // element of the f32x4 this wave owns in tile 16
     float h16 = g.hstate_in[(((size_t) mt * kUnitTiles + u2) * 64 + lane) * 4 + e16];
     P::gi_t gi[2][3], gi16[3];
     {
