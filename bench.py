@@ -547,53 +547,10 @@ def main():
             # `frac_of_peak_by_traffic` (below) the bytes the kernel was measured to move
             stages[name]['limited_by'] = 'VALU issue'
 
-    dominant = max(stages, key=lambda k: stages[k]['avg_launch_ms'] * stages[k]['launches_per_step'])
-    # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command (tools/pmc_run.sh ->
-    # profiles/*_pmc.json; FETCH_SIZE doubled per the gfx950 correction); they cannot be collected inside a timed run.
-    # `traffic_commit` is the source revision the counters were collected on: compare it with HEAD to see staleness.
-    traffic_meta = {}
-    live = None
-    if rank == 0 and world == 1 and not args.no_extra and not args.no_live_traffic:
-        live = live_traffic(args)
-
-    def quote(name, nbytes):
-        stages[name]['traffic'] = nbytes
-        if stages[name]['bound'] == 'hbm':  # against the bytes the kernel was measured to move
-            gbs = nbytes / (stages[name]['avg_launch_ms'] * 1e-3) / 1e9
-            stages[name]['traffic_GBps'] = round(gbs, 1)
-            stages[name]['frac_of_peak_by_traffic'] = round(gbs / HBM_PEAK_GBS, 4)
-    if live:
-        traffic_meta = {'traffic_source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, two passes of this command (3 steps) '
-                                          'started by this run; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch',
-                        'traffic_measured_in_this_run': True}
-        for name in stages:
-            if name in live:
-                quote(name, live[name])
-    else:
-        try:
-            import glob
-            pmc_files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json')))
-            pmc = json.load(open(pmc_files[-1])) if pmc_files else {}
-            wl = pmc.pop('_workload', None)
-            commit = pmc.pop('_commit', None)
-            if wl == {'streams_per_gpu': B, 'frames_per_call': T, 'dtype': args.precision}:
-                traffic_meta = {'traffic_source': os.path.basename(pmc_files[-1]), 'traffic_commit': commit,
-                                'traffic_measured_in_this_run': False}
-                for name in stages:
-                    for entry in pmc.values():
-                        if isinstance(entry, dict) and entry.get('class') == name and 'hbm_bytes' in entry:
-                            quote(name, entry['hbm_bytes'])
-        except Exception:
-            pass
-    roofline = dict(stages[dominant])
-    roofline['kernel'] = dominant
-    roofline.setdefault('traffic', None)
-    roofline.update(traffic_meta)
-
-    # ---- CPU baseline + parity check of what was timed (rank 0 of a single-GPU run only)
+    # ---- CPU baseline + parity check of what was timed (rank 0 of a single-GPU run only).  BEFORE the rocprofv3 passes and the
+    # other operating points: their host threads leave a load average of 15-30 behind, and the CPU leg wants a quiet box
     cpu = None
     parity = None
-    extra = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
         ncores = os.cpu_count() or 1
@@ -659,6 +616,50 @@ def main():
         parity['bars'] = bars
         parity['pass'] = bool(parity['max_lsb'] <= bars['max_lsb'] and parity['within_1_lsb'] >= bars['within_1_lsb'] and
                               parity['mask_rms_vs_fp32_oracle'] < bars['mask_rms'])
+    dominant = max(stages, key=lambda k: stages[k]['avg_launch_ms'] * stages[k]['launches_per_step'])
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command (tools/pmc_run.sh ->
+    # profiles/*_pmc.json; FETCH_SIZE doubled per the gfx950 correction); they cannot be collected inside a timed run.
+    # `traffic_commit` is the source revision the counters were collected on: compare it with HEAD to see staleness.
+    traffic_meta = {}
+    live = None
+    if rank == 0 and world == 1 and not args.no_extra and not args.no_live_traffic:
+        live = live_traffic(args)
+
+    def quote(name, nbytes):
+        stages[name]['traffic'] = nbytes
+        if stages[name]['bound'] == 'hbm':  # against the bytes the kernel was measured to move
+            gbs = nbytes / (stages[name]['avg_launch_ms'] * 1e-3) / 1e9
+            stages[name]['traffic_GBps'] = round(gbs, 1)
+            stages[name]['frac_of_peak_by_traffic'] = round(gbs / HBM_PEAK_GBS, 4)
+    if live:
+        traffic_meta = {'traffic_source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, two passes of this command (3 steps) '
+                                          'started by this run; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch',
+                        'traffic_measured_in_this_run': True}
+        for name in stages:
+            if name in live:
+                quote(name, live[name])
+    else:
+        try:
+            import glob
+            pmc_files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json')))
+            pmc = json.load(open(pmc_files[-1])) if pmc_files else {}
+            wl = pmc.pop('_workload', None)
+            commit = pmc.pop('_commit', None)
+            if wl == {'streams_per_gpu': B, 'frames_per_call': T, 'dtype': args.precision}:
+                traffic_meta = {'traffic_source': os.path.basename(pmc_files[-1]), 'traffic_commit': commit,
+                                'traffic_measured_in_this_run': False}
+                for name in stages:
+                    for entry in pmc.values():
+                        if isinstance(entry, dict) and entry.get('class') == name and 'hbm_bytes' in entry:
+                            quote(name, entry['hbm_bytes'])
+        except Exception:
+            pass
+    roofline = dict(stages[dominant])
+    roofline['kernel'] = dominant
+    roofline.setdefault('traffic', None)
+    roofline.update(traffic_meta)
+
+    extra = None
     if rank == 0 and world == 1 and not args.no_extra:
         extra = extra_points(args, torch, np, koala_amd, model, kb, x, dx, dy, base, local_rank)
     # the constants the fractions are divided by, next to what a plain device-to-device copy reaches on this box

@@ -205,6 +205,35 @@ def test_spec_transform_agrees_with_textbook_ffts(random_model, test_pcm):
         assert np.abs(t1 - y[256:]).max() < 1e-6 * max(1.0, float(np.abs(y).max())) and np.abs(t1 - t2).max() < 1e-6
 
 
+def test_bf16_folds_are_the_unfolded_network_to_rounding(random_model, tmp_path):
+    """bf16 mode since round 4: the front-end is folded into the stage-input GEMMs and b_hh rides in the
+    recurrent GEMM as two bf16 rows.  Both are algebraic identities of the KNS-v1 network: against the same mode with the front-end
+    as a GEMM of its own (KNS_ORACLE_NO_FOLD, one more bf16 rounding point) the samples may differ by rounding only, and the folded
+    form must not be further from the fp32 path than the unfolded one."""
+    import subprocess
+    import sys
+    script = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from oracle import oracle\n"
+        "from koala_amd.workload import synth_streams\n"
+        "x = synth_streams(8, 40, seed=21)\n"
+        "y, m = oracle.Oracle(%r, 8, oracle.PREC_BF16).process_with_mask(x, num_threads=1)\n"
+        "np.savez(sys.argv[1], y=y, m=m)\n"
+    ) % (ROOT, os.path.join(ROOT, 'tests'), random_model)
+    for tag, env in (('folded', {}), ('unfolded', {'KNS_ORACLE_NO_FOLD': '1'})):
+        subprocess.run([sys.executable, '-c', script, str(tmp_path / (tag + '.npz'))], env=dict(os.environ, **env), check=True, timeout=600)
+    a, b = np.load(tmp_path / 'folded.npz'), np.load(tmp_path / 'unfolded.npz')
+    x = synth_streams(8, 40, seed=21)
+    _, ref = oracle.Oracle(random_model, 8, oracle.PREC_FP32).process_with_mask(x, num_threads=1)
+    d = np.abs(a['y'].astype(int) - b['y'].astype(int))
+    assert 0 < d.max() <= 12 and (d <= 2).mean() > 0.99, (int(d.max()), float((d <= 2).mean()))
+
+    def rms(m):
+        return float(np.sqrt(np.mean((m.astype(np.float64) - ref) ** 2)))
+    assert rms(a['m']) < 1e-3 and rms(a['m']) <= rms(b['m']) * 1.05, (rms(a['m']), rms(b['m']))
+
+
 def test_oracle_reproduces_committed_golden_vectors(random_model, prior_gate_model):
     """tests/golden/kns_v1_golden.npz (tools/make_golden.py): the spec pinned as data."""
     g = np.load(os.path.join(GOLDEN, 'kns_v1_golden.npz'))
