@@ -21,8 +21,8 @@ for v in "$@"; do
     *stft*) stft=$v ;;
     *) gru=$v ;;
   esac
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off $flags -Ikoala_amd/csrc -x hip \
-      $stft $gemm $gru koala_amd/csrc/kns_engine.cpp koala_amd/csrc/pv_api.cpp \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -Xarch_host -mfma -Xarch_host -mavx2 $flags -Ikoala_amd/csrc -x hip \
+      $stft $gemm $gru koala_amd/csrc/kns_gruq.hip koala_amd/csrc/kns_engine.cpp koala_amd/csrc/pv_api.cpp \
       -shared -o $lib || exit 1
   i=$((i+1))
 done

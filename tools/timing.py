@@ -7,7 +7,7 @@ lib = os.path.join(ROOT, 'build', 'libpv_koala_timing.so')
 os.makedirs(os.path.dirname(lib), exist_ok=True)
 src = [os.path.join(ROOT, 'koala_amd', 'csrc', f) for f in ('kns_stft.hip', 'kns_gemm.hip', 'kns_gru.hip', 'kns_gruq.hip', 'kns_engine.cpp', 'pv_api.cpp')]
 subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
-                       '-ffp-contract=off', '-DKNS_TIMING', '-x', 'hip'] + src + ['-shared', '-o', lib])
+                       '-ffp-contract=off', '-Xarch_host', '-mfma', '-Xarch_host', '-mavx2', '-DKNS_TIMING', '-x', 'hip'] + src + ['-shared', '-o', lib])
 import koala_amd
 from koala_amd import params
 from koala_amd.workload import synth_streams
