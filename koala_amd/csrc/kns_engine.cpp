@@ -373,11 +373,15 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
             // W_ih:  Wc[k][n] = sum_j w_in[k][j] W_e[j][n],  b'[n] = b_ih[n] + sum_j b_in[j] W_e[j][n]  (j ascending fmaf chains from 0, in
             // fp32), THEN rounded to bf16.  Stage input = [y_prev ; features]; the embedding is never formed.  (oracle: fold_front)
             const std::vector<float> ws = gate_scaled(st.w_ih_a, (size_t) st.d_in + kHidden), bs = gate_scaled(st.b_ih_a, 1);
+            // a fed-forward head of at most kYPadMax values rides BEHIND the features and shares their last k-block (stages 1 and 2):
+            // rows [features ; y_prev], ONE segment of 257 + d_in <= 288 rows; wider ones stay in front with k-blocks of their own
+            d.ypad = st.d_in > 0 && st.d_in <= kYPadMax;
+            const int f0 = d.ypad ? 0 : st.d_in, y0 = d.ypad ? kBins : 0;
             std::vector<float> wf((size_t) (st.d_in + kBins) * G3, 0.0f), bf(G3, 0.0f);
-            memcpy(wf.data(), ws.data(), sizeof(float) * (size_t) st.d_in * G3);
+            memcpy(wf.data() + (size_t) y0 * G3, ws.data(), sizeof(float) * (size_t) st.d_in * G3);
             const float *we = ws.data() + (size_t) st.d_in * G3;
             for (int k = 0; k < kBins; ++k) {
-                float *row = wf.data() + (size_t) (st.d_in + k) * G3;
+                float *row = wf.data() + (size_t) (f0 + k) * G3;
                 for (int j = 0; j < kHidden; ++j) {
                     const float a = p.w_in[(size_t) k * kHidden + j];
                     const float *wr = we + (size_t) j * G3;
@@ -388,8 +392,12 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
                 for (int n = 0; n < G3; ++n) bf[n] = __builtin_fmaf(p.b_in[j], we[(size_t) j * G3 + n], bf[n]);
             for (int n = 0; n < G3; ++n) bf[n] = bs[n] + bf[n];
             std::vector<Seg> segs_f;
-            if (st.d_in) segs_f.push_back({0, st.d_in});
-            segs_f.push_back({st.d_in, kBins});
+            if (d.ypad) {
+                segs_f.push_back({0, kBins + st.d_in});
+            } else {
+                if (st.d_in) segs_f.push_back({0, st.d_in});
+                segs_f.push_back({st.d_in, kBins});
+            }
             auto img = pack_b(wf.data(), G3, segs_f, gt, precision);
             d.w_ih_a = upload(img.data(), img.size());
             auto bimg = pack_bias(bf.data(), gt);
@@ -704,8 +712,11 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     if (!in_place) hist_cur_ ^= 1;
 
     auto gemm = [&](int cls, const void *a0, int nb0, const void *a1, int nb1, const void *w, const float *bias,
-                    void *out, int ntiles, int n_valid, int kind, int taps = 1) {
+                    void *out, int ntiles, int n_valid, int kind, int taps = 1, int pad_nb = 0, int pad_blk = 0, int pad_kk0 = 0) {
         GemmArgs g;
+        g.pad_nb = pad_nb;
+        g.pad_blk = pad_blk;
+        g.pad_kk0 = pad_kk0;
         g.taps = taps;
         g.tap_stride = feat_frame_bytes_;
         g.a0 = a0;
@@ -839,8 +850,9 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     bool head_in_next = false;  // stage s - 1's head has been left to this stage's first layer
     for (int s = 0; s < kStages; ++s) {
         const StageDev &d = sd_[s];
-        const void *yprev = s ? d_y_[s - 1] : nullptr;
-        const int nby = s ? nby_[s - 1] : 0;
+        // (d.ypad: the previous head's few values sit in the padding of the features' last k-block -- no y part of its own)
+        const void *yprev = s && !d.ypad ? d_y_[s - 1] : nullptr;
+        const int nby = s && !d.ypad ? nby_[s - 1] : 0;
         if (small) {
             gru_small(yprev, nby, stage_in, d.w_ih_a, d.b_ih_a, d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_, 0, head_in_next ? &sd_[s - 1] : nullptr);
             gru_small(nullptr, 0, d_hseq_a_, d.w_ih_b, d.b_ih_b, d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_);
@@ -866,6 +878,9 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
                        (small || (quad && nby_[s] <= quad_nb0_max_));
         if (head_in_next)
             ;
+        else if (s < kStages - 1 && sd_[s + 1].ypad)  // into columns 257 ... of the features (k = 1 ... of their block 8)
+            gemm(kClsGemmHead, nullptr, 0, d_hseq_b_, nbh_, d.w_head, d.b_head, feat_now, d.head_tiles, d.head_dim, kOutASigmoid, 1,
+                 /*pad_nb=*/nbf_, /*pad_blk=*/kBins / pi_.kb, /*pad_kk0=*/kBins % pi_.kb);
         else if (s < kStages - 1)
             gemm(kClsGemmHead, nullptr, 0, d_hseq_b_, nbh_, d.w_head, d.b_head, d_y_[s], d.head_tiles, d.head_dim,
                  kOutASigmoid);

@@ -75,6 +75,7 @@ private:
         void *w_ih_a, *w_hh_a, *w_ih_b, *w_hh_b, *w_head;
         float *b_ih_a, *b_hh_a, *b_ih_b, *b_hh_b, *b_head;
         int head_tiles, head_dim;
+        bool ypad;  // this stage's fed-forward input rides in the padding of the features' last k-block (bf16, folded front-end, d_in <= kYPadMax)
     } sd_[kStages]{};
 
     // per-stream state

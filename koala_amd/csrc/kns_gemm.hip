@@ -120,6 +120,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                         else
                             ((f32x4 *) g.out)[idx] = v;
                     }
+                } else if (OUT == kOutASigmoid && g.pad_nb) {  // a narrow head into the padding of an existing matrix (kns_kernels.h)
+                    if (m < mcount && col < g.n_valid) {
+                        typename P::elem_t *dst = (typename P::elem_t *) g.out + ((size_t) (mt0 + m) * g.pad_nb + g.pad_blk) * 64 * P::EPL;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) dst[P::off((lane >> 4) * 4 + i, g.pad_kk0 + col)] = P::cvt(v[i]);
+                    }
                 } else {
                     typename P::elem_t *sc = (typename P::elem_t *) (scratch + m * 1024);
 #pragma unroll
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 }
             }
         }
-        if (kApack) {
+        if (kApack && !(OUT == kOutASigmoid && g.pad_nb)) {
             wave_lds_sync();
             const int out_nb = g.ntiles / NU;
             for (int m = 0; m < mcount; ++m) {
@@ -501,9 +507,18 @@ __global__ __launch_bounds__(512, 2) void gemm_head_kernel(GemmArgs g) {
                         v[i] = nt * 16 + colq < g.n_valid ? x : 0.0f;
                     }
                 }
+                if (g.pad_nb) {  // into the padding of an existing matrix (kns_kernels.h): the valid columns only, 2-byte elements
+                    if (nt * 16 + colq < g.n_valid) {
+                        uint16_t *dst = (uint16_t *) g.out + ((size_t) mt * g.pad_nb + g.pad_blk) * 64 * P::EPL;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) dst[P::off((lane >> 4) * 4 + i, g.pad_kk0 + nt * 16 + colq)] = P::cvt(v[i]);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sc[P::off((lane >> 4) * 4 + i, j * 16 + colq)] = P::cvt(v[i]);
             }
+            if (g.pad_nb) continue;
             wave_lds_sync();
             ((uint4 *) g.out)[((size_t) mt * (NT / 2) + pair) * 64 + lane] = ((const uint4 *) sc)[lane];
             wave_lds_sync();
@@ -809,6 +824,10 @@ void launch_gemm(const GemmArgs &a, hipStream_t s) {
         const dim3 grid(256), block(512);
         if (a.out_kind == kOutAPlain && a.ntiles <= 32) {
             hipLaunchKernelGGL((gemm_wsr_kernel<kOutAPlain, 2>), grid, block, 0, s, a);
+            return;
+        }
+        if (a.out_kind == kOutASigmoid && a.pad_nb && a.ntiles != 2) {
+            launch_gemm_p<PBF16>(a, s);  // (into-the-padding output: the narrow-head kernel and the generic one write it)
             return;
         }
         if (a.out_kind == kOutASigmoid && a.ntiles == 2) {

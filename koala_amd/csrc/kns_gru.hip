@@ -138,8 +138,11 @@ __global__ __launch_bounds__(64 * W, W / 4) void gru_kernel(GruArgs g) {
 // Arithmetic is, operation for operation, what the chunked path does (same MFMA, same k order, gi rounded to its storage
 // type before the gates, same gate formulas per precision), so a stream's samples do not depend on which path ran.
 // kHead: the y part is the previous stage's narrow head, computed here (every workgroup for its m-tile) instead of read
-template <class P, int NB0, bool kHead>  // NB0: k-blocks of the y part of the layer input (everything static: no branch around a load or an MFMA)
+// kPad (with kHead, NB0 == 0): the head's at most kYPadMax values go INTO the features' last k-block, columns 1 ... yvalid of block
+// NBH - 1 ([features ; y_prev] sharing a k-block, kns_layout.h) instead of being a y part in front of x
+template <class P, int NB0, bool kHead, bool kPad = false>  // NB0: k-blocks of the y part of the layer input (everything static: no branch around a load or an MFMA)
 __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
+    static_assert(!kPad || (kHead && NB0 == 0 && P::kPrec == kBf16), "head into the padding: a fused head, no y part, bf16 layout");
     // One workgroup per (unit tile, m-tile), one wave per gate: each wave streams only its gate's weights (a third of the
     // tile's), eight k-blocks of operands requested before the MFMAs that use them; the three accumulator pairs meet
     // in LDS and wave 0 does the gate math.  Every accumulator still sums its k-blocks in ascending order, so the result is
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
     const frag_t *a1 = (const frag_t *) g.a1 + (size_t) mt * NBH * 64 + lane;
     // (kHead) NB0 k-blocks of NPB n-tiles = 1 .. 4 chains of NBH MFMAs, chain c on wave c mod 3; a wave whose slot is past the
     // last chain repeats it (same values to the same words: no branch around the loads or the MFMAs)
-    constexpr int kChains = kHead ? NB0 * P::NPB : 1, kCw = (kChains + 2) / 3;
+    constexpr int kChains = kHead ? (kPad ? P::NPB : NB0 * P::NPB) : 1, kCw = (kChains + 2) / 3;
     frag_t ya[kHead ? NBH : 1], yw[kCw][kHead ? NBH : 1];
     float ybias[kCw];
     if (kHead) {
@@ -243,7 +246,30 @@ __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
     __syncthreads();  // hbuf (and ybuf) complete
 #pragma unroll
     for (int p = 0; p < NBH; ++p) acch = P::mma(((const frag_t *) hbuf)[p * 64 + lane], wh[p], acch);
-    if (kHead) {  // the input-side chain after the barrier: its first NB0 blocks are the head's output
+    if (kHead && kPad) {
+        // the head's values sit in ybuf as an A block of their own (k = column); they belong at k = 1 + column of the features'
+        // last block: both are the first lane group's 16 bytes (k 0..7 of row lane), so lanes 0..15 shift them up by one element
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 yf = __builtin_bit_cast(u32x4, ((const frag_t *) ybuf)[lane]);
+        u32x4 xf = __builtin_bit_cast(u32x4, xa[nb - 1]);
+        // 16-bit elements e0..e7 in four dwords; merged element i (1 <= i <= yvalid) = y element i - 1
+        u32x4 sh;  // y shifted up by one element
+        sh[0] = yf[0] << 16;
+        sh[1] = (yf[0] >> 16) | (yf[1] << 16);
+        sh[2] = (yf[1] >> 16) | (yf[2] << 16);
+        sh[3] = (yf[2] >> 16) | (yf[3] << 16);
+        if (lane < 16) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                // mask of the elements of dword d that take the head's value: elements 2 d, 2 d + 1 with 1 <= element <= yvalid
+                const unsigned lo = (2 * d >= 1 && 2 * d <= g.yvalid) ? 0x0000ffffu : 0u, hi = (2 * d + 1 <= g.yvalid) ? 0xffff0000u : 0u;
+                xf[d] = (xf[d] & ~(lo | hi)) | (sh[d] & (lo | hi));
+            }
+        }
+        const frag_t xlast = __builtin_bit_cast(frag_t, xf);
+#pragma unroll
+        for (int p = 0; p < nb; ++p) acci = P::mma(p == nb - 1 ? xlast : xa[p], wi[p], acci);
+    } else if (kHead) {  // the input-side chain after the barrier: its first NB0 blocks are the head's output
 #pragma unroll
         for (int p = 0; p < nb; ++p) acci = P::mma(p < NB0 ? ((const frag_t *) ybuf)[p * 64 + lane] : xa[p], wi[p], acci);
     }
@@ -285,16 +311,16 @@ __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
 void launch_gru_small(const GruSmallArgs &a, hipStream_t s) {
     dim3 grid(kUnitTiles, a.mtiles);
     auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(192), 0, s, a); };
-    const bool head = a.yw != nullptr && a.nb0 > 0;  // the previous stage's narrow head rides along
+    const bool head = a.yw != nullptr;  // the previous stage's narrow head rides along
     if (a.precision == kBf16) {
         switch (a.nb0) {
-            case 0: go(gru_small_kernel<PBF16, 0, false>); break;
+            case 0: head ? go(gru_small_kernel<PBF16, 0, true, true>) : go(gru_small_kernel<PBF16, 0, false>); break;
             case 1: head ? go(gru_small_kernel<PBF16, 1, true>) : go(gru_small_kernel<PBF16, 1, false>); break;
             default: head ? go(gru_small_kernel<PBF16, 2, true>) : go(gru_small_kernel<PBF16, 2, false>); break;
         }
     } else {
         switch (a.nb0) {
-            case 0: go(gru_small_kernel<PF32, 0, false>); break;
+            case 0: go(gru_small_kernel<PF32, 0, false>); break;  // (fp32 keeps its front-end and every y part in front of x)
             case 1: head ? go(gru_small_kernel<PF32, 1, true>) : go(gru_small_kernel<PF32, 1, false>); break;
             case 2: head ? go(gru_small_kernel<PF32, 2, true>) : go(gru_small_kernel<PF32, 2, false>); break;
             default: head ? go(gru_small_kernel<PF32, 3, true>) : go(gru_small_kernel<PF32, 3, false>); break;

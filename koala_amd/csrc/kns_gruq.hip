@@ -70,11 +70,15 @@ static_assert(kQ1OffGi16 + 1536 <= kQ1Lds && kQ1Lds <= 160 * 1024, "LDS");
 #endif
 constexpr int kQ1Ahead = Q1_AHEAD;  // k-blocks of weights in flight ahead of the MFMAs (a global load takes ~2 300 cycles, a k-block ~430)
 
-template <int NB0, bool kHead>  // kHead: the y part of x is computed here (the previous stage's narrow head), not read
+// YB > 0: the previous stage's narrow head (YB k-blocks = 2 YB n-tiles wide) is computed here instead of read.  With NB0 == YB its
+// output is the y part in front of x ([y_prev ; features]); with NB0 == 0 it is written INTO the features' last k-block, columns
+// 1 ... yvalid of block 8 (kns_layout.h, kYPadMax: [features ; y_prev] sharing a k-block)
+template <int NB0, int YB>
 __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad1_kernel(GruQuadArgs g) {
     typedef bf16x8 frag_t;
     constexpr int NBX = 9 + NB0;
-    static_assert(!kHead || NB0 > 0, "a head feeds a y part");
+    constexpr bool kHead = YB > 0, kPad = YB > 0 && NB0 == 0;
+    static_assert(YB == 0 || NB0 == YB || NB0 == 0, "a head feeds a y part in front of x, or the padding of x's last block");
     __shared__ __attribute__((aligned(16))) char smem[kQ1Lds];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad1_kernel(GruQuadArgs 
     // (kHead) the narrow head's operands first: the four hidden images of the previous stage's layer B -> LDS, and per wave the
     // weights of its chains -- 4 m-tiles x 2 NB0 n-tiles = 8 or 16 chains of 9 MFMAs over the 8 waves: chain ch = wave + 8 q is
     // (m-tile ch & 3, n-tile ch >> 2)
-    constexpr int kCh = kHead ? NB0 : 1;
+    constexpr int kCh = kHead ? YB : 1;
     frag_t yw[kCh][9];
     float ybias[kCh];
     if (kHead) {
@@ -176,8 +180,17 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad1_kernel(GruQuadArgs 
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int blk = 0; blk < 9; ++blk) acc = PBF16::mma(ya[blk * 64], yw[q][blk], acc);
-            uint16_t *sc = (uint16_t *) (smem + kQ1OffXs + (m * 11 + (nt >> 1)) * 1024);
             const bool pad = nt * 16 + colq >= g.yvalid;
+            if (kPad) {  // the valid columns into the staged features' last block (k = 1 + column; the rest of the block stays)
+                uint16_t *sc = (uint16_t *) (smem + kQ1OffXs + (m * 11 + NBX - 1) * 1024);
+                if (!pad) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        sc[PBF16::off((lane >> 4) * 4 + i, 1 + nt * 16 + colq)] = PBF16::cvt(head_sigmoid<PBF16>(acc[i] + ybias[q]));
+                }
+                continue;
+            }
+            uint16_t *sc = (uint16_t *) (smem + kQ1OffXs + (m * 11 + (nt >> 1)) * 1024);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float x = pad ? 0.0f : head_sigmoid<PBF16>(acc[i] + ybias[q]);
@@ -333,17 +346,19 @@ void launch_gru_quad(const GruQuadArgs &a, hipStream_t s) {
         g.quad0 = q0;
         const int n = nquads - q0 < 64 ? nquads - q0 : 64;
         const dim3 grid((n + 7) / 8 * 32), block(64 * kQWaves);  // 32 workgroups = 8 quads, one per XCD
-        const bool head = a.yw != nullptr && a.nb0 > 0;  // the previous stage's narrow head rides along
-        if (a.nb0 == 0)
-            hipLaunchKernelGGL((gru_quad1_kernel<0, false>), grid, block, 0, s, g);
+        const bool head = a.yw != nullptr;  // the previous stage's narrow head rides along
+        if (a.nb0 == 0 && head)  // ... into the padding of the features' last block (one k-block = two n-tiles of head)
+            hipLaunchKernelGGL((gru_quad1_kernel<0, 1>), grid, block, 0, s, g);
+        else if (a.nb0 == 0)
+            hipLaunchKernelGGL((gru_quad1_kernel<0, 0>), grid, block, 0, s, g);
         else if (a.nb0 == 1 && head)
-            hipLaunchKernelGGL((gru_quad1_kernel<1, true>), grid, block, 0, s, g);
+            hipLaunchKernelGGL((gru_quad1_kernel<1, 1>), grid, block, 0, s, g);
         else if (a.nb0 == 1)
-            hipLaunchKernelGGL((gru_quad1_kernel<1, false>), grid, block, 0, s, g);
+            hipLaunchKernelGGL((gru_quad1_kernel<1, 0>), grid, block, 0, s, g);
         else if (head)
-            hipLaunchKernelGGL((gru_quad1_kernel<2, true>), grid, block, 0, s, g);
+            hipLaunchKernelGGL((gru_quad1_kernel<2, 2>), grid, block, 0, s, g);
         else
-            hipLaunchKernelGGL((gru_quad1_kernel<2, false>), grid, block, 0, s, g);
+            hipLaunchKernelGGL((gru_quad1_kernel<2, 0>), grid, block, 0, s, g);
     }
 }
 

@@ -101,6 +101,10 @@ struct GemmArgs {
     // read from a1 + i * tap_stride bytes (the same feature buffer, one frame further on): K = nb0 + taps * nb1 k-blocks
     int taps = 1;
     size_t tap_stride = 0;
+    // kOutASigmoid only, optional: instead of whole A-packed blocks of their own, the n_valid (<= kYPadMax) output columns are
+    // written INTO block pad_blk of an existing A-packed matrix with pad_nb blocks per m-tile, at columns pad_kk0 ... of that block
+    // (2-byte elements; everything else of the block is left alone) -- a narrow head's values in the padding of the feature matrix
+    int pad_nb = 0, pad_blk = 0, pad_kk0 = 0;
 };
 void launch_gemm(const GemmArgs &a, hipStream_t s);
 

@@ -41,6 +41,10 @@ constexpr float kGateScaleN = 2.88539008177792681f;    // 2 log2(e)
 // per-step bias fetch, no accumulator splats (round 4)
 constexpr int kBiasK0 = kHidden;          // = 271: column 15 of unit tile 16; kBiasK0 + 1 = 272: the first column past tile 16
 constexpr unsigned kBf16One = 0x3f80u;
+// bf16 configuration with the folded front-end: a fed-forward head of at most kYPadMax values rides BEHIND the features in their
+// last k-block -- columns kBins ... kBins + d - 1 of the 288 (k = 1 ... d of block 8: the first lane group of the block) -- instead of
+// costing a k-block of its own in the next stage's input GEMM (stages 1 and 2: 1 and 5 values; round 4)
+constexpr int kYPadMax = 7;
 constexpr int kMaxFrontTaps = 5;         // KNS-v1.1: the front-end may see the last N <= 5 feature frames (the reference file has N = 5)
 
 enum Precision { kFp32 = 0, kBf16 = 1 };

@@ -192,14 +192,21 @@ static float *augment_whh(const float *w_hh /* scaled, rounded */, const float *
  *     Wc[k][n] = sum_j w_in[k][j] W_e[j][n]   (j ascending, fmaf from 0),   b'[n] = b_ih[n] + sum_j b_in[j] W_e[j][n]   (likewise)
  * in fp32, THEN rounded to bf16: stage input [y_prev ; features], K = d_in + 257; the embedding is never formed (one GEMM launch,
  * one bf16 rounding and 2 x 257 x 271 flop per frame less).  The engine packs the same matrices (kns_engine.cpp, fold_front). */
+/* A fed-forward head of at most KNS_YPAD_MAX values rides BEHIND the features, [features ; y_prev], where it shares the features'
+ * last 32-wide k-block on the GPU (columns 257 ... of 288) instead of costing a k-block of its own: stages 1 and 2 (1 and 5
+ * values).  Wider ones (stage 3: 40) stay in front, [y_prev ; features]. */
+#define KNS_YPAD_MAX 7
+static int y_behind(int d_in) { return d_in > 0 && d_in <= KNS_YPAD_MAX; }
+
 static void fold_front(const float *w_in, const float *b_in, const float *w_ih /* [d_in + H][3H] scaled, unrounded */,
                        const float *b_ih /* scaled */, int d_in, float **w_out, float **b_out) {
     float *w = (float *) malloc(sizeof(float) * (size_t) (d_in + KNS_BINS) * KNS_G3);
     float *b = (float *) malloc(sizeof(float) * KNS_G3);
-    memcpy(w, w_ih, sizeof(float) * (size_t) d_in * KNS_G3);
+    const int f0 = y_behind(d_in) ? 0 : d_in, y0 = y_behind(d_in) ? KNS_BINS : 0; /* first feature row, first y row */
+    memcpy(w + (size_t) y0 * KNS_G3, w_ih, sizeof(float) * (size_t) d_in * KNS_G3);
     const float *we = w_ih + (size_t) d_in * KNS_G3;
     for (int k = 0; k < KNS_BINS; ++k) {
-        float *row = w + (size_t) (d_in + k) * KNS_G3;
+        float *row = w + (size_t) (f0 + k) * KNS_G3;
         for (int n = 0; n < KNS_G3; ++n) row[n] = 0.0f;
         for (int j = 0; j < KNS_H; ++j) {
             const float a = w_in[(size_t) k * KNS_H + j];
@@ -842,11 +849,16 @@ static void frame_block(const kns_params_t *p, int nb, kns_stream_t **st, const 
         const kns_stage_t *g = &p->st[sg];
         const int K = g->d_in + (p->fold ? KNS_BINS : KNS_H);
         for (int s = 0; s < nb; ++s) {
-            memcpy(&w->xin[s][0], &w->y[s][0], sizeof(float) * (size_t) g->d_in);
-            if (p->fold)
-                memcpy(&w->xin[s][g->d_in], &w->feat[s][0], sizeof(float) * KNS_BINS);
-            else
-                memcpy(&w->xin[s][g->d_in], &w->e[s][0], sizeof(float) * KNS_H);
+            if (p->fold && y_behind(g->d_in)) { /* [features ; y_prev] */
+                memcpy(&w->xin[s][0], &w->feat[s][0], sizeof(float) * KNS_BINS);
+                memcpy(&w->xin[s][KNS_BINS], &w->y[s][0], sizeof(float) * (size_t) g->d_in);
+            } else {
+                memcpy(&w->xin[s][0], &w->y[s][0], sizeof(float) * (size_t) g->d_in);
+                if (p->fold)
+                    memcpy(&w->xin[s][g->d_in], &w->feat[s][0], sizeof(float) * KNS_BINS);
+                else
+                    memcpy(&w->xin[s][g->d_in], &w->e[s][0], sizeof(float) * KNS_H);
+            }
             hp[s] = st[s]->h[2 * sg];
         }
         gru_block(nb, &w->xin[0][0], KNS_H + 64, K, p->fold ? g->w_ih_a_fold : g->w_ih_a, p->fold ? g->b_ih_a_fold : g->b_ih_a,
