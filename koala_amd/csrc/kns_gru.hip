@@ -37,8 +37,12 @@ __global__ __launch_bounds__(64 * W, W / 4) void gru_kernel(GruArgs g) {
         ((elem_t *) hbuf[tid >> 5])[(k / P::KB) * 64 * P::EPL + P::off(tid & 15, k % P::KB)] = (elem_t) kBf16One;
     }
     auto operand_of = [&](float h, int u) -> elem_t {
-        if (P::kPrec == kBf16 && u == kUnitTiles - 1 && colq == 15) return (elem_t) kBf16One;
-        return P::cvt(h);
+        elem_t e = P::cvt(h);
+        if constexpr (P::kPrec == kBf16) {  // (a mask, not a condition: no branch around the stores)
+            const uint32_t one_here = 0u - (uint32_t) ((u == kUnitTiles - 1) & (colq == 15));
+            e = (elem_t) (((uint32_t) e & ~one_here) | (kBf16One & one_here));
+        }
+        return e;
     };
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
@@ -211,12 +215,15 @@ __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
         const int k = v * 16 + colq;
         elem_t *dst = v * 16 < NBH * P::KB ? (elem_t *) hbuf + (k / P::KB) * 64 * P::EPL : (elem_t *) hspare;
         const uint32_t keep = v < kUnitTiles ? 0xffffffffu : 0u;  // (a mask, not a branch: slot 17 is the zero tile)
+        // bf16 configuration: k = 271 (column 15 of tile 16) and k = 272 (column 0 of the empty slot 17) are the constant 1 against
+        // the two bias rows of the packed W_hh (kns_layout.h, kBiasK0).  As a lane MASK, not a condition: with `&&` / `||` hipcc
+        // turned the wave-uniform part into branches around every store, and their merged waits cost the launch a round trip
+        // (4.1 -> 5.4 us per layer at 64 streams)
+        const uint32_t one_here = 0u - (uint32_t) (((v == kUnitTiles - 1) & (colq == 15)) | ((v == kUnitTiles) & (colq == 0)));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             elem_t e = P::cvt(u2f(f2u(hv[q][i]) & keep));
-            // bf16 configuration: k = 271 (column 15 of tile 16) and k = 272 (column 0 of the empty slot 17) are the constant 1
-            // against the two bias rows of the packed W_hh (kns_layout.h, kBiasK0)
-            if (P::kPrec == kBf16 && ((v == kUnitTiles - 1 && colq == 15) || (v == kUnitTiles && colq == 0))) e = (elem_t) kBf16One;
+            if constexpr (P::kPrec == kBf16) e = (elem_t) (((uint32_t) e & ~one_here) | (kBf16One & one_here));
             dst[P::off(rowq + i, k % P::KB)] = e;
         }
     }

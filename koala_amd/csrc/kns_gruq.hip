@@ -158,11 +158,12 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad1_kernel(GruQuadArgs 
             // k = 271 and k = 272 of the operand are the constant 1 that multiplies the two bias rows of the packed W_hh
             // (kns_layout.h, kBiasK0): k = 271 is column 15 of tile 16 -- the high half of the words of lanes colq 14 / 15 --, k = 272
             // column 0 of the otherwise empty slot 17 -- the low half of the words of lanes colq 0 / 1
-            if (t == kUnitTiles) w0 = w1 = colq < 2 ? kBf16One : 0u;
-            if (t == kUnitTiles - 1 && colq >= 14) {
-                w0 = (w0 & 0xffffu) | (kBf16One << 16);
-                w1 = (w1 & 0xffffu) | (kBf16One << 16);
-            }
+            // (as masks, not conditions: `t` is wave-uniform at run time, and hipcc turns such conditions into branches around the
+            // stores, whose merged waits serialise the prologue's one round trip)
+            const unsigned m17 = 0u - (unsigned) (t == kUnitTiles), m16 = (0u - (unsigned) ((t == kUnitTiles - 1) & (colq >= 14))) & 0xffff0000u;
+            const unsigned one17 = colq < 2 ? kBf16One : 0u;
+            w0 = (w0 & ~m17 & ~m16) | (one17 & m17) | ((kBf16One << 16) & m16);
+            w1 = (w1 & ~m17 & ~m16) | (one17 & m17) | ((kBf16One << 16) & m16);
             char *img = smem + kQ1OffHs + m * kQHsBytes + q_tile_off(t) + lane_off;
             *(unsigned *) img = w0;
             *(unsigned *) (img + 16) = w1;

@@ -30,7 +30,7 @@ def main():
     res = {}
     for prec in ('fp32', 'bf16'):
         os.environ['KOALA_AMD_PRECISION'] = prec
-        k = koala_amd.create('key', model_path=model, device='gpu:0')
+        k = koala_amd.create('key', model_path=model, device='gpu:0', library_path=os.environ.get('LATENCY_LIB') or None)
         lib = k._library
         out = (C.c_short * 256)()
         for f in frames[:50]:
