@@ -38,9 +38,10 @@ PV_API pv_status_t pv_koala_batch_process(pv_koala_batch_t *object, const int16_
 
 /* `num_frames` consecutive frames per stream: [num_streams][num_frames*256].  DEVICE pointers: `enhanced` may be the same
  * buffer as `pcm` (in-place) or overlap it partially (detected; the call then takes the stored-spectrum path).  HOST
- * pointers: `enhanced` may equal `pcm` exactly only when the call is not pipelined in sub-chunks (below 4 MiB or
- * num_frames <= 16); larger host calls copy chunks out while later chunks of `pcm` are still unread, so overlapping host
- * buffers are rejected with PV_STATUS_RUNTIME_ERROR (nothing is processed, the streams' state is unchanged). */
+ * pointers: `enhanced` may equal `pcm` EXACTLY in every call (in-place).  A PARTIAL overlap is fine while the call is not
+ * pipelined in sub-chunks (below 4 MiB, or num_frames <= min(16, max_frames_per_call / 2)); larger host calls copy chunks out
+ * while later chunks of `pcm` are still unread, so partially overlapping host buffers are rejected with PV_STATUS_RUNTIME_ERROR
+ * (nothing is processed, the streams' state is unchanged). */
 PV_API pv_status_t pv_koala_batch_process_chunk(pv_koala_batch_t *object, int32_t num_frames, const int16_t *pcm,
                                                 int16_t *enhanced);
 
