@@ -656,6 +656,12 @@ def main():
             pass
     roofline = dict(stages[dominant])
     roofline['kernel'] = dominant
+    # `frac` divides by the launch duration of the EVENT-INSTRUMENTED pass, whose launches are serialised by their event pairs and
+    # a few per cent slower than in the timed pass (`stages_pass`); the same fraction with every class time scaled by
+    # timed step / sum of class times is what the timed run reached
+    timed_ms = elapsed_max / args.steps * 1e3
+    if dev_ms > 0:
+        roofline['frac_scaled_to_timed_pass'] = round(roofline['frac'] * dev_ms / timed_ms, 5)
     roofline.setdefault('traffic', None)
     roofline.update(traffic_meta)
 
