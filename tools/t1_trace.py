@@ -14,9 +14,9 @@ from koala_amd.workload import synth_streams  # noqa: E402
 
 B = int(os.environ.get('T1_B', 4096))
 model = params.ensure_params(os.path.join(ROOT, 'build', 'random_1234.kns'), 'random', 1234)
-x = torch.from_numpy(np.tile(synth_streams(64, 1, 1), (B // 64, 1))).cuda()
+x = torch.from_numpy(np.tile(synth_streams(64, 1, 1), ((B + 63) // 64, 1))[:B]).cuda()
 y = torch.empty_like(x)
-kb = koala_amd.create_batch('k', B, 1, 'bf16', model_path=model)
+kb = koala_amd.create_batch('k', B, 1, os.environ.get('T1_PREC', 'bf16'), model_path=model)
 kb.set_stream(torch.cuda.current_stream().cuda_stream)
 for _ in range(300):
     kb.process_device(1, x.data_ptr(), y.data_ptr())
