@@ -736,8 +736,17 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         if (only < 0 || only == cls) launch_gemm(g, stream_);
         tock(cls);
     };
-    auto gru = [&](const void *whh, const float *bhh, int layer, void *hseq) {
+    auto gru = [&](const void *whh, const float *bhh, int layer, void *hseq, const StageDev *head = nullptr) {
         GruArgs g;
+        if (head) {  // this stage's narrow head inside the launch, into the padding of the feature matrix (kns_kernels.h)
+            g.yw = head->w_head;
+            g.yb = head->b_head;
+            g.yout = feat_now;
+            g.yvalid = head->head_dim;
+            g.y_nb = nbf_;
+            g.y_blk = kBins / pi_.kb;
+            g.y_kk0 = kBins % pi_.kb;
+        }
         g.gi = d_gi_;
         g.whh = whh;
         g.bhh = bhh;
@@ -848,8 +857,10 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
                                    sd_[kStages - 1].head_tiles == kMaskTiles;
     mask_valid_ = !mask_in_synthesis;
     bool head_in_next = false;  // stage s - 1's head has been left to this stage's first layer
+    bool head_in_recurrent = false;  // this stage's head was computed by its layer-B recurrent launch
     for (int s = 0; s < kStages; ++s) {
         const StageDev &d = sd_[s];
+        head_in_recurrent = false;
         // (d.ypad: the previous head's few values sit in the padding of the features' last k-block -- no y part of its own)
         const void *yprev = s && !d.ypad ? d_y_[s - 1] : nullptr;
         const int nby = s && !d.ypad ? nby_[s - 1] : 0;
@@ -870,13 +881,18 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
             if (quad) {
                 gru_quad(nullptr, 0, d_hseq_a_, d.w_ih_b, d.b_ih_b, d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_);
             } else {
+                // multi-frame calls: a narrow head whose values go into the features' padding (stages 0 and 1) is computed by layer
+                // B's recurrent kernel itself, step by step, while the hidden vectors are in LDS: two head launches and two passes
+                // over a hidden sequence (2 x 151 MB at the bench shape) less
+                head_in_recurrent = T > 1 && s < kStages - 1 && sd_[s + 1].ypad && d.head_tiles == pi_.npb && fuse_head_ && !debug_taps_ &&
+                                    !(dev_variant_ & kDevGruStream);
                 gemm(kClsGemmIn, nullptr, 0, d_hseq_a_, nbh_, d.w_ih_b, d.b_ih_b, d_gi_, kGateTiles, 3 * kHidden, kOutGi);
-                gru(d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_);
+                gru(d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_, head_in_recurrent ? &d : nullptr);
             }
         }
         head_in_next = s < kStages - 1 && T == 1 && fuse_head_ && nby_[s] >= 1 && d.head_tiles == pi_.npb * nby_[s] && !debug_taps_ &&
                        (small || (quad && nby_[s] <= quad_nb0_max_));
-        if (head_in_next)
+        if (head_in_next || head_in_recurrent)
             ;
         else if (s < kStages - 1 && sd_[s + 1].ypad)  // into columns 257 ... of the features (k = 1 ... of their block 8)
             gemm(kClsGemmHead, nullptr, 0, d_hseq_b_, nbh_, d.w_head, d.b_head, feat_now, d.head_tiles, d.head_dim, kOutASigmoid, 1,

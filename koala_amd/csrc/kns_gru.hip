@@ -350,16 +350,22 @@ constexpr int kR8Waves = 8;
 // all 13) 154.0.  The stamps' reading that the second MFMA window is bound by the LDS pipe (8 waves x 31 reads) did not hold: an
 // even split is slower, not faster; the first window, where all eight waves start together behind the barrier, absorbs the queue best.
 #ifndef R8_REG0
-#define R8_REG0 14
+#define R8_REG0 15
+#endif
+#ifndef R8_REGS
+#define R8_REGS 42  // (rounds 1-3 and early round 4: 41; the 42nd frees 8 KiB of LDS for the narrow head's weights, below)
 #endif
 constexpr int kR8RegFrags0 = R8_REG0;                  // fragments of the first tile kept in registers ...
-constexpr int kR8RegFrags1 = 41 - R8_REG0;             // ... and of the second
-constexpr int kR8LdsFrags0 = 27 - kR8RegFrags0, kR8LdsFrags1 = 27 - kR8RegFrags1;  // the rest, in LDS (13 per wave in all)
+constexpr int kR8RegFrags1 = R8_REGS - R8_REG0 < 27 ? R8_REGS - R8_REG0 : 27;  // ... and of the second
+static_assert(kR8RegFrags1 <= 27 && kR8RegFrags0 <= 27, "fragments per tile");
+constexpr int kR8LdsFrags0 = 27 - kR8RegFrags0, kR8LdsFrags1 = 27 - kR8RegFrags1;  // the rest, in LDS (12 per wave in all)
 constexpr int kR8Lds = 2 * PBF16::NBH * 1024 + kR8Waves * (kR8LdsFrags0 + kR8LdsFrags1) * 1024 + 27 * 1024;
+constexpr int kR8HeadLds = PBF16::NBH * 1024;          // (kYHead) the narrow head's weight fragments, n-tile 0
 
 // MFMAs of one unit tile whose fragments [first_lds, 27) live in LDS at wl[(i - first_lds)] (i = k_block * 3 + gate) and
 // the rest in wreg[i]; LDS fragments go through a kQ-deep register queue
-template <int kFirstLds, int kQ, int kNReg, bool kChain = false>
+// kChain: a fourth accumulator rides along, one link per k-block with the same A fragment -- w16[blk * kChainStride * 64]
+template <int kFirstLds, int kQ, int kNReg, bool kChain = false, int kChainStride = 3>
 __device__ __forceinline__ void r8_tile_mma(f32x4 (&acc)[3], const bf16x8 *ha, const bf16x8 (&wreg)[kNReg], const bf16x8 *wl,
                                             int lane, f32x4 *a16 = nullptr, const bf16x8 *w16 = nullptr) {
     constexpr int N = 27;
@@ -383,7 +389,7 @@ __device__ __forceinline__ void r8_tile_mma(f32x4 (&acc)[3], const bf16x8 *ha, c
         acc[i % 3] = PBF16::mma(a, b, acc[i % 3]);
         if (kChain && i % 3 == 2) {  // one link of unit tile 16's k chain per k-block, same A fragment
             const bf16x8 c = qc;
-            if (i / 3 + 1 < PBF16::NBH) qc = w16[(i / 3 + 1) * 3 * 64];
+            if (i / 3 + 1 < PBF16::NBH) qc = w16[(i / 3 + 1) * kChainStride * 64];
             *a16 = PBF16::mma(a, c, *a16);
         }
     }
@@ -393,11 +399,17 @@ __device__ __forceinline__ f16x4 buf_load_gi(__amdgpu_buffer_rsrc_t r, unsigned 
     return __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, kGiStreamAux));
 }
 
+// kYHead: the stage's narrow head rides along (GruArgs::yw ...): wave 0 -- the wave with the most slack before the step's barrier
+// (profiles/r04_recurrent_stamps.txt) -- carries its nine MFMAs through its first tile's loop as a fourth accumulator, on the same A
+// fragments (the image of h_{t-1} it multiplies anyway), then the sigmoid and sixteen 2-byte stores: y_{t-1} leaves one step late,
+// y_{T-1} after the loop.  The chain is k-ascending from 0 with the bias after, like gemm_head_kernel's: the same bits.
+template <bool kYHead>
 __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs g) {
     typedef PBF16 P;
     typedef P::frag_t frag_t;
     constexpr int NBH = P::NBH;
-    __shared__ __attribute__((aligned(16))) char smem[kR8Lds + 3 * 1024 + 16];
+    __shared__ __attribute__((aligned(16))) char smem[kR8Lds + 3 * 1024 + 16 + (kYHead ? kR8HeadLds : 0)];
+    frag_t *wlh = (frag_t *) (smem + kR8Lds + 3 * 1024 + 16);  // (kYHead) [9][64]: the head's n-tile 0
     char *hbuf0 = smem, *hbuf1 = smem + NBH * 1024;
     frag_t *wl1 = (frag_t *) (smem + 2 * NBH * 1024);                                   // [8 waves][13][64]: first tile's, then second tile's
     frag_t *wl16 = (frag_t *) (smem + 2 * NBH * 1024 + kR8Waves * (kR8LdsFrags0 + kR8LdsFrags1) * 1024);  // [27][64], i = blk * 3 + gate
@@ -445,6 +457,11 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     for (int i = wave; i < 27; i += kR8Waves)
         __builtin_amdgcn_global_load_lds((gptr_t) (whh + ((size_t) (u2 * 3 + i % 3) * NBH + i / 3) * 64 + lane),
                                          (lptr_t) (wl16 + i * 64), 16, 0, 0);
+    if (kYHead) {
+        for (int i = wave; i < NBH; i += kR8Waves)
+            __builtin_amdgcn_global_load_lds((gptr_t) ((const frag_t *) g.yw + (size_t) i * 64 + lane), (lptr_t) (wlh + i * 64), 16, 0, 0);
+    }
+    const float ybias = kYHead ? g.yb[colq] : 0.0f;
     frag_t w0[kR8RegFrags0], w1[kR8RegFrags1];
 #pragma unroll
     for (int i = 0; i < kR8RegFrags0; ++i) w0[i] = whh[((size_t) (u0 * 3 + i % 3) * NBH + i / 3) * 64 + lane];
@@ -515,6 +532,18 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
         const frag_t x1 = src[i1];
         buf_store_frag(hs, lane < 8 ? i1 * 16u : 0x7fffff00u, x1);  // lanes 8..63: past the descriptor's end, dropped
     };
+    // (kYHead, wave 0) y of the hidden vector whose image the chain just multiplied -> frame `frame` of the destination matrix
+    const size_t y_frame_bytes = (size_t) g.mtiles * g.y_nb * 1024;
+    // (in a wave-0 branch, against the rule that no vector-memory operation of the step sits inside one: the unconditional form --
+    // every wave issuing the stores through a descriptor that is empty for waves 1..7 -- costs registers the kernel does not have
+    // (256 VGPRs + 24 B of scratch) and measured 171.7 us per launch against 156.5)
+    auto emit_y = [&](const f32x4 &ya, int frame) {
+        uint16_t *dst = (uint16_t *) ((char *) g.yout + (size_t) frame * y_frame_bytes + ((size_t) mt * g.y_nb + g.y_blk) * 1024);
+        if (colq < g.yvalid) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[P::off(rowq + i, g.y_kk0 + colq)] = P::cvt(head_sigmoid<PBF16>(ya[i] + ybias));
+        }
+    };
     for (int t = 0; t < g.T; ++t) {
         KNS_STAMP(0);
         KNS_STAMP_AT(9, 8);  // steady-state step length = (stamp 10 - stamp 9) / 16
@@ -549,7 +578,13 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
         KNS_STAMP(1);
         f32x4 acc[3];
         acc_init(acc, u0);
-        r8_tile_mma<kR8RegFrags0, R8C_Q, kR8RegFrags0>(acc, ha, w0, wl0w, lane);
+        if (kYHead && wave == 0) {  // ... with the head's chain on h_{t-1} (at t = 0: h_{-1}, into frame 0's slot, rewritten at t = 1)
+            f32x4 ya = f32x4{0.f, 0.f, 0.f, 0.f};
+            r8_tile_mma<kR8RegFrags0, R8C_Q, kR8RegFrags0, true, 1>(acc, ha, w0, wl0w, lane, &ya, wlh + lane);
+            emit_y(ya, t > 0 ? t - 1 : 0);
+        } else {
+            r8_tile_mma<kR8RegFrags0, R8C_Q, kR8RegFrags0>(acc, ha, w0, wl0w, lane);
+        }
         KNS_STAMP(2);
         gates(0, acc);
         KNS_STAMP(3);
@@ -588,6 +623,13 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
         __syncthreads();
         KNS_STAMP(8);
     }
+    if (kYHead && wave == 0) {  // the head of the last hidden vector
+        const frag_t *hl = (const frag_t *) ((g.T & 1) ? hbuf1 : hbuf0);
+        f32x4 ya = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int blk = 0; blk < NBH; ++blk) ya = P::mma(hl[blk * 64 + lane], wlh[blk * 64 + lane], ya);
+        emit_y(ya, g.T - 1);
+    }
     publish((const frag_t *) ((g.T & 1) ? hbuf1 : hbuf0), (const char *) g.hseq + ((size_t) (g.T - 1) * g.mtiles + mt) * NBH * 1024);
     ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u0) * 64 + lane] = hreg[0];
     ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u1) * 64 + lane] = hreg[1];
@@ -596,8 +638,10 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
 
 void launch_gru(const GruArgs &a, hipStream_t s) {
     const bool stream_weights = (a.dev & kDevGruStream) != 0;  // A/B switch (developer build only)
-    if (a.precision == kBf16 && !stream_weights)
-        hipLaunchKernelGGL(gru_resident8_kernel, dim3(a.mtiles), dim3(64 * kR8Waves), 0, s, a);
+    if (a.precision == kBf16 && !stream_weights && a.yw)
+        hipLaunchKernelGGL(gru_resident8_kernel<true>, dim3(a.mtiles), dim3(64 * kR8Waves), 0, s, a);
+    else if (a.precision == kBf16 && !stream_weights)
+        hipLaunchKernelGGL(gru_resident8_kernel<false>, dim3(a.mtiles), dim3(64 * kR8Waves), 0, s, a);
     else if (a.precision == kBf16)
         hipLaunchKernelGGL((gru_kernel<PBF16, 8>), dim3(a.mtiles), dim3(512), 0, s, a);
     else

@@ -119,6 +119,14 @@ struct GruArgs {
     void *hseq;         // A-packed [T][mtiles][nbh] blocks, out
     int T, mtiles, precision;
     int dev = 0;  // DevVariant bits
+    // optional (bf16 resident kernel): the stage's NARROW head (at most kYPadMax values) computed inside this launch, step by step,
+    // from the hidden vectors while they are in LDS -- y_t = sigmoid(h_t . W_head + b_head) written into columns y_kk0 ... of block
+    // y_blk of an A-packed matrix with y_nb blocks per m-tile and T x mtiles m-tiles (the feature matrix' padding, kns_layout.h): no
+    // head launch, no second pass over the hidden sequence
+    const void *yw = nullptr;    // B-packed head weights, n-tile 0: [nbh] blocks
+    const float *yb = nullptr;   // [16]
+    void *yout = nullptr;
+    int yvalid = 0, y_nb = 0, y_blk = 0, y_kk0 = 0;
 };
 void launch_gru(const GruArgs &a, hipStream_t s);
 
