@@ -1,7 +1,9 @@
 // kns_engine.cpp -- parameter loading/packing, HBM workspace and the per-chunk kernel sequence of the KNS-v1 engine.
 //
-// Sequence for one call of B streams x T frames (23 launches, independent of T):
+// Sequence for one call of B streams x T frames (fp32: 23 launches, independent of T):
 //   analysis -> front-end GEMM -> 4 x { input GEMM A -> recurrent A -> input GEMM B -> recurrent B -> head GEMM } -> synthesis
+// (bf16 configuration, one-frame front-end: 20 -- the front-end is folded into the stage-input GEMMs and the narrow heads of stages 0
+// and 1 ride in their layer-B recurrent launches; the dispatch table stands in front of Engine::run_device)
 // which is the batched form of what one pv_koala_process call does for one stream and one frame
 // (reference include/pv_koala.h:65-80; stage structure per lib/common/koala_params.pv).
 #include "kns_engine.h"
@@ -647,8 +649,10 @@ bool Engine::reset(const uint8_t *host_mask, std::string *err) {
 //   |-------------------------------|-----------------------------------------------------|--------------------------------------|
 //   | spectrum                      | stored by analysis, read by synthesis (in place)    | T > 1: rebuilt from the PCM by the   |
 //   |                               |                                                     | synthesis kernel (not if in == out)  |
-//   | front-end GEMM                | inside the analysis launch (one-frame front-end)    | gemm_wsr / gemm_front5 / gemm_kernel |
-//   | narrow heads 1 / 5 / 40       | inside the next stage's first layer launch          | gemm_head_kernel                     |
+//   | front-end GEMM                | none: folded into the stage-input GEMMs (one-frame  | bf16, T > 1: none either; fp32 and   |
+//   |                               | front-end); five-frame: gemm_front5_t1_kernel       | KNS-v1.1: gemm_wsr / front5 / generic |
+//   | narrow heads 1 / 5 / 40       | inside the next stage's first layer launch          | bf16, T > 1: 1 and 5 inside their    |
+//   |                               |                                                     | layer-B recurrent launch; gemm_head  |
 //   | mask head                     | inside the synthesis launch                         | gemm_wsr_kernel                      |
 //   | analysis / synthesis segments | one                                                 | ~4 / ~2 workgroups per CU (>= 4 frames) |
 //   Host-pointer calls: >= 4 MiB and more than min(16, max_frames / 2) frames -> sub-chunks on three streams; T = 1 -> hipGraph replay.
