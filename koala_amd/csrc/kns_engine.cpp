@@ -272,6 +272,8 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     dev_synth_seg_ = dev_int("KOALA_AMD_SYNTH_SEG", 0);
     dev_small_mt_ = dev_int("KOALA_AMD_SMALL_MT", 0);
     dev_steps_mt_ = dev_int("KOALA_AMD_STEPS_MT", 192);
+    dev_wave_mt_ = dev_int("KOALA_AMD_WAVE_MT", 0);
+    dev_wave_group_ = dev_int("KOALA_AMD_WAVE_GROUP", 0);
     // One-frame calls of large batches: a GRU layer as ONE launch fused over CU quads (kns_gruq.hip, gru_quad1_kernel), bit-identical
     // to the two-kernel form -- a CU pulls a quarter of W_ih and W_hh (300 KiB) per layer instead of a half of one and all of the
     // other (~740 KiB): 128 against 222 us per 4096-stream frame step.  (The multi-frame form of that decomposition measured slower
@@ -432,6 +434,7 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     d_tail_[1] = (float *) dalloc((size_t) Bpad_ * kFrame * 4, true);
     d_hstate_[0] = (float *) dalloc((size_t) kGruLayers * mtb * kUnitTiles * 1024, true);
     d_hstate_[1] = (float *) dalloc((size_t) kGruLayers * mtb * kUnitTiles * 1024, true);
+    d_hprev_ = dalloc((size_t) kGruLayers * mtb * nbh_ * 1024, true);  // the state in operand form (wavefront calls, frame 0)
     d_rmask_ = (uint8_t *) dalloc((size_t) Bpad_, true);
 
     // ---- activation workspace
@@ -656,7 +659,7 @@ bool Engine::reset(const uint8_t *host_mask, std::string *err) {
 //   | mask head                     | inside the synthesis launch                         | gemm_wsr_kernel                      |
 //   | analysis / synthesis segments | one                                                 | ~4 / ~2 workgroups per CU (>= 4 frames) |
 //   Host-pointer calls: >= 4 MiB and more than min(16, max_frames / 2) frames -> sub-chunks on three streams; T = 1 -> hipGraph replay.
-enum Route { kRouteChunked = 0, kRouteSmall = 1, kRouteSmallSteps = 2, kRouteQuad1 = 3 };
+enum Route { kRouteChunked = 0, kRouteSmall = 1, kRouteSmallSteps = 2, kRouteQuad1 = 3, kRouteWave = 4 };
 
 bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string *err, bool allow_recompute) {
     const int mtb = Bpad_ / 16;
@@ -785,17 +788,16 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     const int steps_mt = dev_steps_mt_;
     // (fp32 only: the bf16 recurrent kernel keeps its weights on chip and is faster than 8 us per frame and layer even
     // with 16 workgroups -- 11.3 vs 5.2 M frames/s at 256 streams; the fp32 one streams them: 1.2 vs 2.8 M)
-    const bool small_steps = T > 1 && mtb <= steps_mt && prec_ != kBf16 && !no_small_;
-    auto gru_small = [&](const void *a0, int nb0, const void *a1, const void *wih, const float *bih, const void *whh,
-                         const float *bhh, int layer, void *hseq, int t = 0, const StageDev *head = nullptr) {
+    auto small_args = [&](const void *a0, int nb0, const void *a1, const void *wih, const float *bih, const void *whh,
+                          const float *bhh, int layer, void *hseq, int t, const StageDev *head) {
         GruSmallArgs g;
-        if (head) {  // the narrow head of the stage before, inside this launch (one-frame calls)
-            g.yh = d_hseq_b_;
+        const size_t frame = (size_t) t * mtb * 1024;  // bytes of one k-block column of A per frame
+        if (head) {  // the narrow head of the stage before, inside this launch
+            g.yh = (const char *) d_hseq_b_ + frame * nbh_;
             g.yw = head->w_head;
             g.yb = head->b_head;
             g.yvalid = head->head_dim;
         }
-        const size_t frame = (size_t) t * mtb * 1024;  // bytes of one k-block column of A per frame
         g.a0 = a0 ? (const char *) a0 + frame * nb0 : nullptr;
         g.a1 = (const char *) a1 + frame * nbh_;
         g.wih = wih;
@@ -808,11 +810,60 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         g.nb0 = nb0;
         g.mtiles = mtb;
         g.precision = prec_;
+        return g;
+    };
+    auto gru_small = [&](const void *a0, int nb0, const void *a1, const void *wih, const float *bih, const void *whh,
+                         const float *bhh, int layer, void *hseq, int t = 0, const StageDev *head = nullptr) {
+        const GruSmallArgs g = small_args(a0, nb0, a1, wih, bih, whh, bhh, layer, hseq, t, head);
         tick(kClsGru);
         launch_gru_small(g, stream_);
         tock(kClsGru);
     };
-
+    // Multi-frame calls of few streams, as a WAVEFRONT over (pipeline stage, frame): the stages are the eight GRU layers with the
+    // three narrow heads between them; stage i of frame t needs stage i - 1 of frame t and (a layer) its own frame t - 1, so launch k
+    // runs the items with i + t = k side by side (kns_gru.hip, gru_wave_kernel) -- T + 10 launches of up to 8 x 17 x groups workgroups
+    // instead of 8 T launches of 17 x mtb (kRouteSmallSteps) or of mtb (the chunked recurrent kernels).  The per-frame slots of the two
+    // hidden-sequence buffers, of the y operands and of the features' padding are reused stage after stage exactly as in the
+    // layer-by-layer order: within a frame the stages still run one after the other.
+    char *feat_call = (char *) d_feat_ + (size_t) (taps_ - 1) * feat_frame_bytes_;
+    auto wave_item = [&](int i, int t) {
+        const int s = i / 3, r = i % 3;
+        const StageDev &d = sd_[s];
+        const size_t frame = (size_t) t * mtb * 1024;
+        GruWaveItem it;
+        if (r == 2) {  // the head of stage s
+            it.g.yh = (const char *) d_hseq_b_ + frame * nbh_;
+            it.g.yw = d.w_head;
+            it.g.yb = d.b_head;
+            it.g.yvalid = d.head_dim;
+            it.g.mtiles = mtb;
+            it.g.precision = prec_;
+            if (sd_[s + 1].ypad) {
+                it.chains = 1;
+                it.pad = 1;
+                it.yout = feat_call + frame * nbf_;
+                it.y_nb = nbf_;
+                it.y_blk = kBins / pi_.kb;
+                it.y_kk0 = kBins % pi_.kb;
+            } else {
+                it.chains = d.head_tiles;
+                it.yout = (char *) d_y_[s] + frame * nby_[s];
+                it.y_nb = nby_[s];
+            }
+        } else if (r == 1) {
+            it.g = small_args(nullptr, 0, d_hseq_a_, d.w_ih_b, d.b_ih_b, d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_, t, nullptr);
+            it.hprev = t ? (const char *) d_hseq_b_ + (frame - (size_t) mtb * 1024) * nbh_ : (const char *) d_hprev_ + (size_t) (2 * s + 1) * mtb * nbh_ * 1024;
+        } else {
+            it.hprev = t ? (const char *) d_hseq_a_ + (frame - (size_t) mtb * 1024) * nbh_ : (const char *) d_hprev_ + (size_t) (2 * s) * mtb * nbh_ * 1024;
+            const bool y = s && !d.ypad;
+            it.g = small_args(y ? d_y_[s - 1] : nullptr, y ? nby_[s - 1] : 0, fold_ ? (const void *) feat_call : (const void *) d_e_, d.w_ih_a,
+                              d.b_ih_a, d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_, t, nullptr);
+        }
+        return it;
+    };
+    bool wave = T > 1 && mtb <= dev_wave_mt_ && !no_small_ && !debug_taps_ && (only < 0 || only == kClsGru);
+    for (int s = 0; wave && s < kStages - 1; ++s)
+        wave = sd_[s + 1].ypad ? sd_[s].head_dim <= 16 : (nby_[s] >= 1 && nby_[s] <= 3 && sd_[s].head_tiles == pi_.npb * nby_[s]);
     // One-frame bf16 calls whose m-tiles come in whole quads (from 60 m-tiles on): a GRU layer is ONE launch (kns_gruq.hip) -- input
     // GEMM, recurrent GEMM and gates fused over CU quads.  Same arithmetic as the two-kernel form, bit for bit
     // (tests/test_gpu_parity.py::test_alternative_kernels_give_identical_pcm).
@@ -844,7 +895,8 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         tock(kClsGru);
     };
 
-    last_route_ = small ? kRouteSmall : small_steps ? kRouteSmallSteps : quad ? kRouteQuad1 : kRouteChunked;
+    const bool small_steps = T > 1 && mtb <= steps_mt && prec_ != kBf16 && !no_small_ && !wave;
+    last_route_ = small ? kRouteSmall : wave ? kRouteWave : small_steps ? kRouteSmallSteps : quad ? kRouteQuad1 : kRouteChunked;
     // front-end: e = features . W_in + b_in
     // (bf16 with a one-frame front-end: folded into the stage-input GEMMs, which read the features themselves -- no launch, no `e`)
     if (!fold_)
@@ -862,7 +914,38 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     mask_valid_ = !mask_in_synthesis;
     bool head_in_next = false;  // stage s - 1's head has been left to this stage's first layer
     bool head_in_recurrent = false;  // this stage's head was computed by its layer-B recurrent launch
-    for (int s = 0; s < kStages; ++s) {
+    if (wave) {
+        // m-tiles per workgroup: about two workgroups per CU when the pipeline is full
+        int mgroup = (kWaveItems - 3) * kUnitTiles * mtb / 1024;
+        if (dev_wave_group_ > 0) mgroup = dev_wave_group_;
+        if (mgroup < 1) mgroup = 1;
+        tick(kClsGru);
+        launch_gru_wave_prev(d_hstate_[hs_cur_], d_hprev_, kGruLayers * mtb, prec_, stream_);
+        tock(kClsGru);
+        for (int k = 0; k < T + kWaveItems - 1; ++k) {
+            GruWaveArgs w;
+            w.mgroup = mgroup;
+            w.layer_wgs = kUnitTiles * ((mtb + mgroup - 1) / mgroup);
+            for (int x = 0; x < 8; ++x) w.layer_item[x] = w.head_item[x] = -1;
+            int n = 0;
+            for (int i = k < T ? 0 : k - T + 1; i <= k && i < kWaveItems; ++i) {
+                w.item[n] = wave_item(i, k - i);
+                // layer l on XCD l; the head of stage s beside that stage's layer B
+                if (i % 3 == 2)
+                    w.head_item[2 * (i / 3) + 1] = n;
+                else
+                    w.layer_item[2 * (i / 3) + i % 3] = n;
+                ++n;
+            }
+            tick(kClsGru);
+            launch_gru_wave(w, prec_, mtb, stream_);
+            tock(kClsGru);
+        }
+        if (!mask_in_synthesis)
+            gemm(kClsGemmHead, nullptr, 0, d_hseq_b_, nbh_, sd_[kStages - 1].w_head, sd_[kStages - 1].b_head, d_mask_,
+                 sd_[kStages - 1].head_tiles, kBins, kOutMask);
+    }
+    for (int s = 0; s < kStages && !wave; ++s) {
         const StageDev &d = sd_[s];
         head_in_recurrent = false;
         // (d.ypad: the previous head's few values sit in the padding of the features' last k-block -- no y part of its own)
@@ -939,7 +1022,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     tick(kClsSynthesis);
     if (only < 0 || only == kClsSynthesis) launch_synthesis(sy, stream_);
     tock(kClsSynthesis);
-    hs_cur_ = small_steps ? (hs_cur_ + T) & 1 : hs_cur_ ^ 1;
+    hs_cur_ = small_steps || wave ? (hs_cur_ + T) & 1 : hs_cur_ ^ 1;
     if (!in_place) tail_cur_ ^= 1;
 
     hipError_t e = hipGetLastError();

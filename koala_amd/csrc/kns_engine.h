@@ -82,6 +82,7 @@ private:
     int16_t *d_hist_[2] = {nullptr, nullptr};
     int hist_cur_ = 0;
     float *d_tail_[2] = {nullptr, nullptr}, *d_hstate_[2] = {nullptr, nullptr};
+    void *d_hprev_ = nullptr;  // the recurrent state as A-packed operand blocks [layer][m-tile][nbh] (kRouteWave)
     int tail_cur_ = 0, hs_cur_ = 0;
     uint8_t *d_rmask_ = nullptr;
     // front-end context (front_taps > 1): features of the last front_taps - 1 frames (A-packed, one "frame" = mtiles x nbf
@@ -109,7 +110,7 @@ private:
     hipGraphExec_t frame_graph_[8] = {};  // one per combination of the hidden-state / history / tail ping-pong indices
     bool use_graph_ = true, no_small_ = false, no_zero_copy_ = false, no_recompute_ = false, debug_taps_ = false;
     // developer switches (all read once in init() through dev_env(): compiled out of the product library)
-    int dev_variant_ = 0, dev_only_class_ = -1, dev_analysis_seg_ = 0, dev_synth_seg_ = 0, dev_small_mt_ = 0, dev_steps_mt_ = 192;
+    int dev_variant_ = 0, dev_only_class_ = -1, dev_analysis_seg_ = 0, dev_synth_seg_ = 0, dev_small_mt_ = 0, dev_steps_mt_ = 192, dev_wave_mt_ = 0, dev_wave_group_ = 0;
     // one-frame calls: GRU layers fused over CU quads (kns_gruq.hip); narrow heads / front-end / mask head inside their consumers
     bool use_quad_ = true;
     int quad_nb0_max_ = 2;

@@ -144,8 +144,11 @@ __global__ __launch_bounds__(64 * W, W / 4) void gru_kernel(GruArgs g) {
 // kHead: the y part is the previous stage's narrow head, computed here (every workgroup for its m-tile) instead of read
 // kPad (with kHead, NB0 == 0): the head's at most kYPadMax values go INTO the features' last k-block, columns 1 ... yvalid of block
 // NBH - 1 ([features ; y_prev] sharing a k-block, kns_layout.h) instead of being a y part in front of x
+// (the body is shared by the one-layer launch below and by gru_wave_kernel, which runs several layers' workgroups in one launch;
+// u, mt: the workgroup's unit tile and m-tile; the four LDS areas are the caller's)
 template <class P, int NB0, bool kHead, bool kPad = false>  // NB0: k-blocks of the y part of the layer input (everything static: no branch around a load or an MFMA)
-__global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
+__device__ __forceinline__ void gru_small_body(const GruSmallArgs &g, const int u, const int mt, char *hbuf, char *hspare, char *ybuf,
+                                               f32x4 (*xch)[3][64]) {
     static_assert(!kPad || (kHead && NB0 == 0 && P::kPrec == kBf16), "head into the padding: a fused head, no y part, bf16 layout");
     // One workgroup per (unit tile, m-tile), one wave per gate: each wave streams only its gate's weights (a third of the
     // tile's), eight k-blocks of operands requested before the MFMAs that use them; the three accumulator pairs meet
@@ -154,13 +157,8 @@ __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
     typedef typename P::frag_t frag_t;
     typedef typename P::elem_t elem_t;
     constexpr int NBH = P::NBH;
-    __shared__ __attribute__((aligned(16))) char hbuf[NBH * 1024];
-    __shared__ __attribute__((aligned(16))) char hspare[1024];
-    __shared__ __attribute__((aligned(16))) char ybuf[(NB0 > 0 ? NB0 : 1) * 1024];  // (kHead) the y part as A fragments
-    __shared__ f32x4 xch[2][3][64];  // [input | recurrent][gate][lane]
     const int lane = threadIdx.x & 63;
     const int gt = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // this wave's gate: r, z, n
-    const int u = blockIdx.x, mt = blockIdx.y;
     const int colq = lane & 15, rowq = (lane >> 4) * 4;
     constexpr int nb = NB0 + NBH;
 
@@ -313,6 +311,242 @@ __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
     elem_t *hs = (elem_t *) g.hseq + ((size_t) mt * NBH + k / P::KB) * 64 * P::EPL;
 #pragma unroll
     for (int i = 0; i < 4; ++i) hs[P::off(rowq + i, k % P::KB)] = P::cvt(hnew[i]);
+}
+
+template <class P, int NB0, bool kHead, bool kPad = false>
+__global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
+    __shared__ __attribute__((aligned(16))) char hbuf[P::NBH * 1024];
+    __shared__ __attribute__((aligned(16))) char hspare[1024];
+    __shared__ __attribute__((aligned(16))) char ybuf[(NB0 > 0 ? NB0 : 1) * 1024];  // (kHead) the y part as A fragments
+    __shared__ f32x4 xch[2][3][64];  // [input | recurrent][gate][lane]
+    gru_small_body<P, NB0, kHead, kPad>(g, blockIdx.x, blockIdx.y, hbuf, hspare, ybuf, xch);
+}
+
+// ---- multi-frame calls of few streams: a WAVEFRONT over (layer, frame).  Layer l of frame t needs layer l - 1 of frame t and layer
+// l of frame t - 1, so the items of one anti-diagonal -- one per pipeline stage: the eight GRU layers and the three narrow heads
+// between the stages -- are independent and run side by side in ONE launch (blockIdx.y = item): T + 10 launches per call instead
+// of 8 T, each with enough workgroups for the chip.  A workgroup owns (item, unit tile, group of m-tiles): the three gate waves
+// keep their W_ih and W_hh fragments in registers for the whole group (a CU pulls them once per launch instead of once per m-tile),
+// the m-tile's operands -- x blocks from memory, h_{t-1} converted from its fp32 tiles -- are staged through LDS by the three waves
+// together, and two workgroups per CU cover each other's memory round trips.  The arithmetic is gru_small_body's, operation for
+// operation (same chains, same k order, gi rounded to its storage type, same gate formulas), so the PCM does not depend on the route.
+template <class P, int NB0>
+__device__ __forceinline__ void gru_wave_layer(const GruWaveItem &it, const int u, const int m0, const int m1, const int role, char *obuf,
+                                               f32x4 (*xch)[3][64]) {
+    typedef typename P::frag_t frag_t;
+    typedef typename P::elem_t elem_t;
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    constexpr int NBH = P::NBH, nb = NB0 + NBH, nop = nb + NBH;  // operand blocks of an m-tile: y, x, h_{t-1}
+    constexpr int kBufBytes = (2 * P::NBH + 3) * 1024;
+    const GruSmallArgs &g = it.g;
+    const int lane = threadIdx.x & 63;
+    const int colq = lane & 15, rowq = (lane >> 4) * 4;
+    // Four waves: roles 0..2 are the gates r, z, n -- each keeps its gate's W_ih and W_hh fragments in registers for the whole group
+    // of m-tiles and runs the two MFMA chains of an m-tile; role 3 does the gate arithmetic of the m-tile BEFORE, under those
+    // MFMAs.  Two barriers per m-tile: B1 (the operand blocks are in LDS; the exchange area is free), B2 (the pre-activations are in
+    // the exchange area; the other operand buffer is free).
+    if (role == 3) {
+        const float br = g.bhh[(u * 3 + 0) * 16 + colq], bz = g.bhh[(u * 3 + 1) * 16 + colq], bn = g.bhh[(u * 3 + 2) * 16 + colq];
+        f32x4 gin[3], gh[3], hown = ((const f32x4 *) g.hstate_in)[((size_t) m0 * kUnitTiles + u) * 64 + lane];
+        auto gates = [&](int mt) {
+            f32x4 hnew;
+            if (P::kPrec == kBf16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hnew[i] = gate_elem_bf16(gin[0][i], gin[1][i], gin[2][i], gh[0][i], gh[1][i], gh[2][i], hown[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float r = kns_sigmoid(gin[0][i] + (gh[0][i] + br));
+                    float z = kns_sigmoid(gin[1][i] + (gh[1][i] + bz));
+                    float n = kns_tanh(__builtin_fmaf(r, gh[2][i] + bn, gin[2][i]));
+                    hnew[i] = __builtin_fmaf(z, hown[i] - n, n);
+                }
+            }
+            ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u) * 64 + lane] = hnew;
+            const int k = u * 16 + colq;
+            elem_t *hs = (elem_t *) g.hseq + ((size_t) mt * NBH + k / P::KB) * 64 * P::EPL;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hs[P::off(rowq + i, k % P::KB)] = P::cvt(hnew[i]);
+        };
+        for (int mt = m0; mt < m1; ++mt) {
+            __syncthreads();  // B1
+            if (mt > m0) {
+                gates(mt - 1);
+                hown = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u) * 64 + lane];
+            }
+            __syncthreads();  // B2
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                gin[q] = xch[0][q][lane];
+                gh[q] = xch[1][q][lane];
+            }
+        }
+        __syncthreads();  // (the B1 the MFMA waves' epilogue does not have: keeps the barrier counts equal -- see below)
+        gates(m1 - 1);
+        return;
+    }
+    const int gt = role;
+    frag_t wi[nb], wh[NBH];
+    {
+        const frag_t *wih = (const frag_t *) g.wih + (size_t) (u * 3 + gt) * nb * 64 + lane;
+        const frag_t *whh = (const frag_t *) g.whh + (size_t) (u * 3 + gt) * NBH * 64 + lane;
+#pragma unroll
+        for (int p = 0; p < nb; ++p) wi[p] = wih[(size_t) p * 64];
+#pragma unroll
+        for (int p = 0; p < NBH; ++p) wh[p] = whh[(size_t) p * 64];
+    }
+    const float bi = g.bih[(u * 3 + gt) * 16 + colq];
+    // An m-tile's operand blocks go from memory straight into LDS (no registers, no conversion: h_{t-1} is read in operand form -- the
+    // hidden sequence's slot of frame t - 1, or the call's converted state for its first frame), block p by wave p mod 3, into the
+    // buffer the MFMAs of the m-tile before do not read.
+    constexpr int kMine = (nop + 2) / 3;
+    auto request = [&](int mt, char *buf) {
+#pragma unroll
+        for (int q = 0; q < kMine; ++q) {
+            const int p = gt + 3 * q;
+            if (p < nop) {  // (wave-uniform)
+                const frag_t *src = p < NB0 ? (const frag_t *) g.a0 + ((size_t) mt * NB0 + p) * 64
+                                  : p < nb  ? (const frag_t *) g.a1 + ((size_t) mt * NBH + (p - NB0)) * 64
+                                            : (const frag_t *) it.hprev + ((size_t) mt * NBH + (p - nb)) * 64;
+                __builtin_amdgcn_global_load_lds((gptr_t) (src + lane), (lptr_t) (buf + p * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto landed = [&](char *buf) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's blocks have landed
+        if constexpr (P::kPrec == kBf16) {
+            // k = 271 and k = 272 of the h operand are the constant 1 against the two bias rows of the packed W_hh (kns_layout.h, kBiasK0):
+            // written by the wave that requested h's last block, after it has landed (elements 15 and 16 of rows 0 .. 15)
+            if ((nop - 1) % 3 == gt && lane < 32)
+                ((elem_t *) (buf + (nop - 1) * 1024))[P::off(lane & 15, 15 + (lane >> 4))] = (elem_t) kBf16One;
+        }
+    };
+    request(m0, obuf);
+    landed(obuf);
+    int cur = 0;
+    for (int mt = m0; mt < m1; ++mt) {
+        char *buf = obuf + cur * kBufBytes;
+        __syncthreads();  // B1
+        cur ^= 1;
+        if (mt + 1 < m1) request(mt + 1, obuf + cur * kBufBytes);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acci = f32x4{0.f, 0.f, 0.f, 0.f}, acch = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < nb; ++p) acci = P::mma(((const frag_t *) buf)[p * 64 + lane], wi[p], acci);
+#pragma unroll
+        for (int p = 0; p < NBH; ++p) acch = P::mma(((const frag_t *) buf)[(nb + p) * 64 + lane], wh[p], acch);
+        {
+            f32x4 v = acci;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = v[i] + bi;
+            xch[0][gt][lane] = P::from_gi(P::to_gi(v));
+            xch[1][gt][lane] = acch;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B2 (not __syncthreads: the next m-tile's blocks stay in flight)
+        landed(obuf + cur * kBufBytes);
+    }
+    __syncthreads();  // the gate wave's last B1
+}
+
+// the state of a call's first frame in operand form: fp32 tiles [layer][m-tile][17][64][4] -> A-packed [layer][m-tile][NBH] blocks
+// (the padding columns stay as allocated: zero)
+template <class P>
+__global__ __launch_bounds__(64) void gru_wave_prev_kernel(const float *hstate, void *hprev) {
+    typedef typename P::elem_t elem_t;
+    const int lane = threadIdx.x, v = blockIdx.x;
+    const size_t mtl = blockIdx.y;  // layer * mtiles + m-tile
+    const int colq = lane & 15, rowq = (lane >> 4) * 4;
+    const f32x4 h = ((const f32x4 *) hstate)[(mtl * kUnitTiles + v) * 64 + lane];
+    const int k = v * 16 + colq;
+    elem_t *dst = (elem_t *) hprev + (mtl * P::NBH + k / P::KB) * 64 * P::EPL;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[P::off(rowq + i, k % P::KB)] = P::cvt(h[i]);
+}
+
+void launch_gru_wave_prev(const float *hstate, void *hprev, int layers_x_mtiles, int precision, hipStream_t s) {
+    dim3 grid(kUnitTiles, layers_x_mtiles);
+    if (precision == kBf16)
+        hipLaunchKernelGGL(gru_wave_prev_kernel<PBF16>, grid, dim3(64), 0, s, hstate, hprev);
+    else
+        hipLaunchKernelGGL(gru_wave_prev_kernel<PF32>, grid, dim3(64), 0, s, hstate, hprev);
+}
+
+// a narrow head as an item of the wavefront: y = sigmoid(h_B . W_head + b_head) of one m-tile, rounded to the operand type, columns
+// >= yvalid zero -- what gemm_head_kernel stores; chain c (an n-tile of 16 columns, NBH k-blocks) on wave c mod 4.  y_nb > 0: into
+// the y operand [m-tiles][y_nb] blocks; pad: into columns y_kk0 ... of block y_blk of the features (bf16, at most kYPadMax values)
+template <class P>
+__device__ __forceinline__ void gru_wave_head(const GruWaveItem &it, const int mt) {
+    typedef typename P::frag_t frag_t;
+    typedef typename P::elem_t elem_t;
+    constexpr int NBH = P::NBH;
+    const GruSmallArgs &g = it.g;
+    const int lane = threadIdx.x & 63;
+    const int gt = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int colq = lane & 15, rowq = (lane >> 4) * 4;
+    for (int c = gt; c < it.chains; c += 4) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        frag_t ya[NBH], yw[NBH];
+#pragma unroll
+        for (int p = 0; p < NBH; ++p) ya[p] = ((const frag_t *) g.yh)[((size_t) mt * NBH + p) * 64 + lane];
+#pragma unroll
+        for (int p = 0; p < NBH; ++p) yw[p] = ((const frag_t *) g.yw)[((size_t) c * NBH + p) * 64 + lane];
+        const float ybias = g.yb[c * 16 + colq];
+#pragma unroll
+        for (int p = 0; p < NBH; ++p) acc = P::mma(ya[p], yw[p], acc);
+        const int col = c * 16 + colq;
+        const bool past = col >= g.yvalid;
+        if (it.pad) {
+            elem_t *dst = (elem_t *) it.yout + ((size_t) mt * it.y_nb + it.y_blk) * 64 * P::EPL;
+            if (!past) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dst[P::off(rowq + i, it.y_kk0 + col)] = P::cvt(head_sigmoid<P>(acc[i] + ybias));
+            }
+        } else {
+            elem_t *dst = (elem_t *) it.yout + ((size_t) mt * it.y_nb + c / P::NPB) * 64 * P::EPL;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                dst[P::off(rowq + i, (c % P::NPB) * 16 + colq)] = P::cvt(past ? 0.0f : head_sigmoid<P>(acc[i] + ybias));
+        }
+    }
+}
+
+template <class P>
+__global__ __launch_bounds__(256, 2) void gru_wave_kernel(GruWaveArgs w) {
+    __shared__ __attribute__((aligned(16))) char obuf[2 * (2 * P::NBH + 3) * 1024];  // two operand buffers of [y | x | h] blocks
+    __shared__ f32x4 xch[2][3][64];
+    // Workgroups are dealt to the eight XCDs round-robin by their linear index, and each XCD has its own L2: every workgroup of a
+    // layer runs on ONE XCD (layer l on XCD l), so an XCD pulls one layer's weights per launch (1.8 MB in fp32) and serves its
+    // workgroups from L2 -- dealt across the chip, every XCD's 4 MB L2 would see all eight layers' 14 MB and keep none.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int li = w.layer_item[xcd], hi = w.head_item[xcd];
+    if (slot >= w.layer_wgs) {  // a head: one workgroup per m-tile
+        if (hi >= 0 && slot - w.layer_wgs < w.item[hi].g.mtiles) gru_wave_head<P>(w.item[hi], slot - w.layer_wgs);
+        return;
+    }
+    if (li < 0) return;
+    const GruWaveItem &it = w.item[li];
+    const int mtiles = it.g.mtiles;
+    const int u = slot % kUnitTiles, grp = slot / kUnitTiles;
+    const int m0 = grp * w.mgroup, m1 = m0 + w.mgroup < mtiles ? m0 + w.mgroup : mtiles;
+    // (the gate wave sits on a different SIMD from workgroup to workgroup, so that the CU's four matrix pipes share the MFMA waves)
+    const int role = __builtin_amdgcn_readfirstlane(((threadIdx.x >> 6) + slot) & 3);
+    switch (__builtin_amdgcn_readfirstlane(it.g.nb0)) {
+        case 0: gru_wave_layer<P, 0>(it, u, m0, m1, role, obuf, xch); break;
+        case 1: gru_wave_layer<P, 1>(it, u, m0, m1, role, obuf, xch); break;
+        case 2: gru_wave_layer<P, 2>(it, u, m0, m1, role, obuf, xch); break;
+        default: gru_wave_layer<P, 3>(it, u, m0, m1, role, obuf, xch); break;
+    }
+}
+
+void launch_gru_wave(const GruWaveArgs &w, int precision, int mtiles, hipStream_t s) {
+    bool heads = false;
+    for (int x = 0; x < 8; ++x) heads = heads || w.head_item[x] >= 0;
+    dim3 grid(8 * (w.layer_wgs + (heads ? mtiles : 0)));
+    if (precision == kBf16)
+        hipLaunchKernelGGL(gru_wave_kernel<PBF16>, grid, dim3(256), 0, s, w);
+    else
+        hipLaunchKernelGGL(gru_wave_kernel<PF32>, grid, dim3(256), 0, s, w);
 }
 
 void launch_gru_small(const GruSmallArgs &a, hipStream_t s) {

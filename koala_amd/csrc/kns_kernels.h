@@ -152,6 +152,28 @@ struct GruSmallArgs {
 };
 void launch_gru_small(const GruSmallArgs &a, hipStream_t s);
 
+// the wavefront form of multi-frame calls (kns_gru.hip, gru_wave_kernel): the items of one anti-diagonal of (pipeline stage, frame)
+struct GruWaveItem {
+    GruSmallArgs g;     // a GRU layer of one frame: as for launch_gru_small (a0 = the y operand of that frame, read from memory)
+    const void *hprev = nullptr;  // A-packed h_{t-1} of this layer [m-tiles][NBH]: the hidden sequence's slot of frame t - 1, or the converted state
+    // a narrow head of one frame instead (chains > 0): g.yh / yw / yb / yvalid, g.mtiles; its n-tiles = chains
+    int chains = 0;
+    int pad = 0;        // 1: the values go into columns y_kk0 ... of block y_blk of `yout` = the features [m-tiles][y_nb] (bf16)
+    void *yout = nullptr;  // else: A-packed y operand [m-tiles][y_nb]
+    int y_nb = 0, y_blk = 0, y_kk0 = 0;
+};
+constexpr int kWaveItems = 11;  // eight layers + three heads
+struct GruWaveArgs {
+    GruWaveItem item[kWaveItems];
+    int layer_item[8];  // per XCD: the layer item its workgroups run (-1: none in this launch)
+    int head_item[8];   // per XCD: a head item behind the layer's workgroups (-1: none)
+    int layer_wgs;      // workgroups of a layer item = 17 x ceil(mtiles / mgroup)
+    int mgroup;         // m-tiles per workgroup of a layer item
+};
+void launch_gru_wave(const GruWaveArgs &w, int precision, int mtiles, hipStream_t s);
+// the recurrent state [layers x mtiles][17 tiles] as A-packed operand blocks [layers x mtiles][NBH] (a wavefront call's frame 0)
+void launch_gru_wave_prev(const float *hstate, void *hprev, int layers_x_mtiles, int precision, hipStream_t s);
+
 // ---- a whole GRU layer of ONE frame in one launch: input GEMM + recurrent GEMM + gates fused over CU quads (kns_gruq.hip).
 // Four workgroups on one XCD own four m-tiles (64 streams); workgroup c pulls the columns of W_ih AND W_hh that belong to
 // hidden units 64 c .. 64 c + 63 (and serves unit tile 16 for m-tile c) and computes its quarter of h' for all four m-tiles.
