@@ -29,7 +29,10 @@ namespace kns {
 static __device__ unsigned long long g_kns_timing[8 * 16];  // [wave][stamp] of workgroup 0 at step 5
 #define KNS_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && t == 5) g_kns_timing[(threadIdx.x >> 6) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define KNS_STAMP_AT(i, step) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && t == (step)) g_kns_timing[(threadIdx.x >> 6) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// (gru_wave_kernel: role r of the workgroup in slot 1 of XCD 3, second m-tile of its group, in the launch the engine marks)
+#define KNS_WSTAMP(i) do { if (dbg_stamp && (threadIdx.x & 63) == 0 && mt == m0 + 1) g_kns_timing[role * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
+#define KNS_WSTAMP(i) do { } while (0)
 #define KNS_STAMP(i) do { } while (0)
 #define KNS_STAMP_AT(i, step) do { } while (0)
 #endif
@@ -129,6 +132,14 @@ struct PF32 {
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
         return c;
     }
+    // two independent chains advanced by one k-block each, their MFMAs alternating (a chain's next MFMA needs its previous result)
+    static __device__ __forceinline__ void mma2(frag_t a0, frag_t b0, f32x4 &c0, frag_t a1, frag_t b1, f32x4 &c1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], b0[q], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], b1[q], c1, 0, 0, 0);
+        }
+    }
     static __device__ __forceinline__ int off(int rc, int kk) { return pack_off_f32(rc, kk); }
     static __device__ __forceinline__ elem_t cvt(float v) { return v; }
     static __device__ __forceinline__ gi_t to_gi(f32x4 v) { return v; }
@@ -146,6 +157,10 @@ struct PBF16 {
     typedef uint16_t elem_t;
     static __device__ __forceinline__ f32x4 mma(frag_t a, frag_t b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma2(frag_t a0, frag_t b0, f32x4 &c0, frag_t a1, frag_t b1, f32x4 &c1) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, c1, 0, 0, 0);
     }
     static __device__ __forceinline__ int off(int rc, int kk) { return pack_off_bf16(rc, kk); }
     static __device__ __forceinline__ elem_t cvt(float v) { return f2bf(v); }

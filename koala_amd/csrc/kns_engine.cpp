@@ -3,7 +3,8 @@
 // Sequence for one call of B streams x T frames (fp32: 23 launches, independent of T):
 //   analysis -> front-end GEMM -> 4 x { input GEMM A -> recurrent A -> input GEMM B -> recurrent B -> head GEMM } -> synthesis
 // (bf16 configuration, one-frame front-end: 20 -- the front-end is folded into the stage-input GEMMs and the narrow heads of stages 0
-// and 1 ride in their layer-B recurrent launches; the dispatch table stands in front of Engine::run_device)
+// and 1 ride in their layer-B recurrent launches; several frames of few streams: T + 14 -- the layers as a wavefront over (stage,
+// frame); the dispatch table stands in front of Engine::run_device)
 // which is the batched form of what one pv_koala_process call does for one stream and one frame
 // (reference include/pv_koala.h:65-80; stage structure per lib/common/koala_params.pv).
 #include "kns_engine.h"
@@ -272,7 +273,7 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     dev_synth_seg_ = dev_int("KOALA_AMD_SYNTH_SEG", 0);
     dev_small_mt_ = dev_int("KOALA_AMD_SMALL_MT", 0);
     dev_steps_mt_ = dev_int("KOALA_AMD_STEPS_MT", 192);
-    dev_wave_mt_ = dev_int("KOALA_AMD_WAVE_MT", 0);
+    dev_wave_mt_ = dev_int("KOALA_AMD_WAVE_MT", -1);  // -1: the measured limits; 0: never
     dev_wave_group_ = dev_int("KOALA_AMD_WAVE_GROUP", 0);
     // One-frame calls of large batches: a GRU layer as ONE launch fused over CU quads (kns_gruq.hip, gru_quad1_kernel), bit-identical
     // to the two-kernel form -- a CU pulls a quarter of W_ih and W_hh (300 KiB) per layer instead of a half of one and all of the
@@ -639,11 +640,16 @@ bool Engine::reset(const uint8_t *host_mask, std::string *err) {
 //   | bf16          | 1        | >= 60 and mtb % 4 == 0                | kRouteQuad1: gru_quad1_kernel, one launch per layer; stage    |
 //   |               |          |                                       |   inputs wider than 2 k-blocks: input GEMM + recurrent kernel |
 //   | bf16          | 1        | > 192 and mtb % 4 != 0                | kRouteChunked                                                 |
-//   | bf16          | > 1      | any                                   | kRouteChunked: gemm_ws2 (m-tiles in multiples of 256 x stage; |
+//   | bf16          | > 1      | <= 32                                 | kRouteWave: gru_wave_kernel, T + 10 launches: the (stage,     |
+//   |               |          |                                       |   frame) items of one anti-diagonal side by side, one layer   |
+//   |               |          |                                       |   per XCD, narrow heads as items of their own                 |
+//   | bf16          | > 1      | > 32                                  | kRouteChunked: gemm_ws2 (m-tiles in multiples of 256 x stage; |
 //   |               |          |                                       |   the rest through gemm_kernel) + gru_resident8_kernel        |
 //   | fp32          | 1        | <= 256                                | kRouteSmall                                                   |
 //   | fp32          | 1        | > 256                                 | kRouteChunked: gemm_kernel + gru_kernel<PF32, 8>              |
-//   | fp32          | > 1      | <= 192                                | kRouteSmallSteps: gru_small_kernel frame by frame (T launches |
+//   | fp32          | > 1      | <= 4; <= 16 from T = 6, <= 32 from 12,| kRouteWave                                                   |
+//   |               |          |   <= 128 from 24                      |                                                              |
+//   | fp32          | > 1      | otherwise <= 192                      | kRouteSmallSteps: gru_small_kernel frame by frame (T launches |
 //   |               |          |                                       |   per layer; the chunked recurrence would occupy mtb CUs)     |
 //   | fp32          | > 1      | > 192                                 | kRouteChunked                                                 |
 //
@@ -861,7 +867,13 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         }
         return it;
     };
-    bool wave = T > 1 && mtb <= dev_wave_mt_ && !no_small_ && !debug_taps_ && (only < 0 || only == kClsGru);
+    // Where it wins (measured against the other routes, tools/wave_check.py): bf16 up to 512 streams at any T > 1 (32 frames: 32.4
+    // against 24.1 M frames/s at 512 streams, 38.8 against 43.3 at 1 024 -- there the chunked kernels' resident weights win); fp32 --
+    // whose launches are MFMA-bound, so the ten launches that fill and drain the pipeline cost more -- from T frames on that grow with
+    // the batch (256 streams: 0.45 against 0.39 ms at T = 4, 0.57 against 0.69 at T = 8; 2 048 streams x 32: 7.2 against 8.7 ms;
+    // 4 096 x 32: 13.6 against 13.4)
+    const bool wave_wins = prec_ == kBf16 ? mtb <= 32 : (mtb <= 4 || (mtb <= 16 && T >= 6) || (mtb <= 32 && T >= 12) || (mtb <= 128 && T >= 24));
+    bool wave = T > 1 && (dev_wave_mt_ >= 0 ? mtb <= dev_wave_mt_ : wave_wins) && !no_small_ && !debug_taps_ && (only < 0 || only == kClsGru);
     for (int s = 0; wave && s < kStages - 1; ++s)
         wave = sd_[s + 1].ypad ? sd_[s].head_dim <= 16 : (nby_[s] >= 1 && nby_[s] <= 3 && sd_[s].head_tiles == pi_.npb * nby_[s]);
     // One-frame bf16 calls whose m-tiles come in whole quads (from 60 m-tiles on): a GRU layer is ONE launch (kns_gruq.hip) -- input
@@ -916,15 +928,19 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     bool head_in_recurrent = false;  // this stage's head was computed by its layer-B recurrent launch
     if (wave) {
         // m-tiles per workgroup: about two workgroups per CU when the pipeline is full
-        int mgroup = (kWaveItems - 3) * kUnitTiles * mtb / 1024;
+        // m-tiles per workgroup (an XCD holds 64 workgroups at a time, a layer has 17 per group; measured best: 1 up to 64 streams,
+        // 3 up to 256, 6 up to 512, 8 beyond -- short groups balance the CUs, long ones pull the weights less often)
+        int mgroup = mtb <= 4 ? 1 : mtb <= 16 ? 3 : mtb <= 32 ? 6 : 8;
         if (dev_wave_group_ > 0) mgroup = dev_wave_group_;
-        if (mgroup < 1) mgroup = 1;
         tick(kClsGru);
         launch_gru_wave_prev(d_hstate_[hs_cur_], d_hprev_, kGruLayers * mtb, prec_, stream_);
         tock(kClsGru);
         for (int k = 0; k < T + kWaveItems - 1; ++k) {
             GruWaveArgs w;
             w.mgroup = mgroup;
+#ifdef KNS_TIMING
+            w.stamp = k == T / 2 + 5;
+#endif
             w.layer_wgs = kUnitTiles * ((mtb + mgroup - 1) / mgroup);
             for (int x = 0; x < 8; ++x) w.layer_item[x] = w.head_item[x] = -1;
             int n = 0;

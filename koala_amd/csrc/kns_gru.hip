@@ -332,7 +332,7 @@ __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
 // operation (same chains, same k order, gi rounded to its storage type, same gate formulas), so the PCM does not depend on the route.
 template <class P, int NB0>
 __device__ __forceinline__ void gru_wave_layer(const GruWaveItem &it, const int u, const int m0, const int m1, const int role, char *obuf,
-                                               f32x4 (*xch)[3][64]) {
+                                               f32x4 *xch, const bool dbg_stamp) {
     typedef typename P::frag_t frag_t;
     typedef typename P::elem_t elem_t;
     typedef const __attribute__((address_space(1))) void *gptr_t;
@@ -343,23 +343,47 @@ __device__ __forceinline__ void gru_wave_layer(const GruWaveItem &it, const int 
     const int lane = threadIdx.x & 63;
     const int colq = lane & 15, rowq = (lane >> 4) * 4;
     // Four waves: roles 0..2 are the gates r, z, n -- each keeps its gate's W_ih and W_hh fragments in registers for the whole group
-    // of m-tiles and runs the two MFMA chains of an m-tile; role 3 does the gate arithmetic of the m-tile BEFORE, under those
-    // MFMAs.  Two barriers per m-tile: B1 (the operand blocks are in LDS; the exchange area is free), B2 (the pre-activations are in
-    // the exchange area; the other operand buffer is free).
+    // of m-tiles and runs the two MFMA chains of an m-tile, nothing else; role 3 requests the NEXT m-tile's operand blocks and does
+    // the gate arithmetic of the m-tile BEFORE, both under those MFMAs.  Two barriers per m-tile: B1 (the operand blocks are in LDS,
+    // the exchange area is free), B2 (the pre-activations are in the exchange area; the other operand buffer is free); between B2
+    // and the next B1 role 3 only takes the pre-activations into registers and waits for the blocks it requested.
     if (role == 3) {
-        const float br = g.bhh[(u * 3 + 0) * 16 + colq], bz = g.bhh[(u * 3 + 1) * 16 + colq], bn = g.bhh[(u * 3 + 2) * 16 + colq];
-        f32x4 gin[3], gh[3], hown = ((const f32x4 *) g.hstate_in)[((size_t) m0 * kUnitTiles + u) * 64 + lane];
+        // An m-tile's operand blocks go from memory straight into LDS (no registers, no conversion: h_{t-1} is read in operand form --
+        // the hidden sequence's slot of frame t - 1, or the call's converted state for its first frame), into the buffer the MFMAs
+        // in flight do not read.
+        auto request = [&](int mt, char *buf) {
+#pragma unroll
+            for (int p = 0; p < nop; ++p) {
+                const frag_t *src = p < NB0 ? (const frag_t *) g.a0 + ((size_t) mt * NB0 + p) * 64
+                                  : p < nb  ? (const frag_t *) g.a1 + ((size_t) mt * NBH + (p - NB0)) * 64
+                                            : (const frag_t *) it.hprev + ((size_t) mt * NBH + (p - nb)) * 64;
+                __builtin_amdgcn_global_load_lds((gptr_t) (src + lane), (lptr_t) (buf + p * 1024), 16, 0, 0);
+            }
+        };
+        auto landed = [&](char *buf) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (P::kPrec == kBf16) {
+                // k = 271 and k = 272 of the h operand are the constant 1 against the two bias rows of the packed W_hh (kns_layout.h,
+                // kBiasK0): elements 15 and 16 of rows 0 .. 15 of h's last block, written once it has landed
+                if (lane < 32) ((elem_t *) (buf + (nop - 1) * 1024))[P::off(lane & 15, 15 + (lane >> 4))] = (elem_t) kBf16One;
+            }
+        };
+        // the exchange area, bf16: [input | recurrent][gate] accumulators; fp32 (LDS is the resource there: two workgroups per CU
+        // leave 4 KiB): the sums the gate formulas start with, made by the MFMA waves -- r: gi + (gh + b_r), z: gi + (gh + b_z),
+        // n: gi and gh + b_n -- same operations in the same order as gru_small_body's
+        constexpr int kXW = P::kPrec == kBf16 ? 6 : 4;
+        f32x4 pre[kXW], hown = ((const f32x4 *) g.hstate_in)[((size_t) m0 * kUnitTiles + u) * 64 + lane];
         auto gates = [&](int mt) {
             f32x4 hnew;
-            if (P::kPrec == kBf16) {
+            if constexpr (P::kPrec == kBf16) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) hnew[i] = gate_elem_bf16(gin[0][i], gin[1][i], gin[2][i], gh[0][i], gh[1][i], gh[2][i], hown[i]);
+                for (int i = 0; i < 4; ++i) hnew[i] = gate_elem_bf16(pre[0][i], pre[1][i], pre[2][i], pre[3][i], pre[4][i], pre[5][i], hown[i]);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float r = kns_sigmoid(gin[0][i] + (gh[0][i] + br));
-                    float z = kns_sigmoid(gin[1][i] + (gh[1][i] + bz));
-                    float n = kns_tanh(__builtin_fmaf(r, gh[2][i] + bn, gin[2][i]));
+                    float r = kns_sigmoid(pre[0][i]);
+                    float z = kns_sigmoid(pre[1][i]);
+                    float n = kns_tanh(__builtin_fmaf(r, pre[3][i], pre[2][i]));
                     hnew[i] = __builtin_fmaf(z, hown[i] - n, n);
                 }
             }
@@ -369,20 +393,31 @@ __device__ __forceinline__ void gru_wave_layer(const GruWaveItem &it, const int 
 #pragma unroll
             for (int i = 0; i < 4; ++i) hs[P::off(rowq + i, k % P::KB)] = P::cvt(hnew[i]);
         };
+        auto take = [&]() {  // the pre-activations of the m-tile the MFMA waves have just finished; then the exchange area is theirs again
+#pragma unroll
+            for (int q = 0; q < kXW; ++q) pre[q] = xch[q * 64 + lane];
+        };
+        request(m0, obuf);
+        landed(obuf);
+        int cur = 0;
         for (int mt = m0; mt < m1; ++mt) {
+            KNS_WSTAMP(0);
             __syncthreads();  // B1
+            KNS_WSTAMP(1);
+            cur ^= 1;
+            if (mt + 1 < m1) request(mt + 1, obuf + cur * kBufBytes);
             if (mt > m0) {
                 gates(mt - 1);
                 hown = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u) * 64 + lane];
             }
-            __syncthreads();  // B2
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                gin[q] = xch[0][q][lane];
-                gh[q] = xch[1][q][lane];
-            }
+            KNS_WSTAMP(2);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B2 (not __syncthreads: the requested blocks stay in flight)
+            KNS_WSTAMP(3);
+            take();
+            landed(obuf + cur * kBufBytes);
+            KNS_WSTAMP(4);
         }
-        __syncthreads();  // (the B1 the MFMA waves' epilogue does not have: keeps the barrier counts equal -- see below)
+        __syncthreads();  // (the MFMA waves' last barrier)
         gates(m1 - 1);
         return;
     }
@@ -396,57 +431,56 @@ __device__ __forceinline__ void gru_wave_layer(const GruWaveItem &it, const int 
 #pragma unroll
         for (int p = 0; p < NBH; ++p) wh[p] = whh[(size_t) p * 64];
     }
-    const float bi = g.bih[(u * 3 + gt) * 16 + colq];
-    // An m-tile's operand blocks go from memory straight into LDS (no registers, no conversion: h_{t-1} is read in operand form -- the
-    // hidden sequence's slot of frame t - 1, or the call's converted state for its first frame), block p by wave p mod 3, into the
-    // buffer the MFMAs of the m-tile before do not read.
-    constexpr int kMine = (nop + 2) / 3;
-    auto request = [&](int mt, char *buf) {
-#pragma unroll
-        for (int q = 0; q < kMine; ++q) {
-            const int p = gt + 3 * q;
-            if (p < nop) {  // (wave-uniform)
-                const frag_t *src = p < NB0 ? (const frag_t *) g.a0 + ((size_t) mt * NB0 + p) * 64
-                                  : p < nb  ? (const frag_t *) g.a1 + ((size_t) mt * NBH + (p - NB0)) * 64
-                                            : (const frag_t *) it.hprev + ((size_t) mt * NBH + (p - nb)) * 64;
-                __builtin_amdgcn_global_load_lds((gptr_t) (src + lane), (lptr_t) (buf + p * 1024), 16, 0, 0);
-            }
-        }
-    };
-    auto landed = [&](char *buf) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's blocks have landed
-        if constexpr (P::kPrec == kBf16) {
-            // k = 271 and k = 272 of the h operand are the constant 1 against the two bias rows of the packed W_hh (kns_layout.h, kBiasK0):
-            // written by the wave that requested h's last block, after it has landed (elements 15 and 16 of rows 0 .. 15)
-            if ((nop - 1) % 3 == gt && lane < 32)
-                ((elem_t *) (buf + (nop - 1) * 1024))[P::off(lane & 15, 15 + (lane >> 4))] = (elem_t) kBf16One;
-        }
-    };
-    request(m0, obuf);
-    landed(obuf);
+    const float bi = g.bih[(u * 3 + gt) * 16 + colq], bh = g.bhh[(u * 3 + gt) * 16 + colq];
     int cur = 0;
     for (int mt = m0; mt < m1; ++mt) {
         char *buf = obuf + cur * kBufBytes;
+        KNS_WSTAMP(0);
         __syncthreads();  // B1
+        KNS_WSTAMP(1);
         cur ^= 1;
-        if (mt + 1 < m1) request(mt + 1, obuf + cur * kBufBytes);
-        __builtin_amdgcn_sched_barrier(0);
+        // the two chains side by side (neither waits for its own previous MFMA), the operand fragments of block p + 1 read from LDS
+        // under the MFMAs of block p; each chain still sums its k-blocks in ascending order
         f32x4 acci = f32x4{0.f, 0.f, 0.f, 0.f}, acch = f32x4{0.f, 0.f, 0.f, 0.f};
+        const frag_t *bl = (const frag_t *) buf + lane;
 #pragma unroll
-        for (int p = 0; p < nb; ++p) acci = P::mma(((const frag_t *) buf)[p * 64 + lane], wi[p], acci);
+        for (int p = 0; p < NB0; ++p) acci = P::mma(bl[p * 64], wi[p], acci);
+        frag_t xn = bl[NB0 * 64], hn = bl[nb * 64];
 #pragma unroll
-        for (int p = 0; p < NBH; ++p) acch = P::mma(((const frag_t *) buf)[(nb + p) * 64 + lane], wh[p], acch);
+        for (int p = 0; p < NBH; ++p) {
+            const frag_t xc = xn, hc = hn;
+            if (p + 1 < NBH) {
+                xn = bl[(NB0 + p + 1) * 64];
+                hn = bl[(nb + p + 1) * 64];
+            }
+            P::mma2(xc, wi[NB0 + p], acci, hc, wh[p], acch);
+        }
         {
             f32x4 v = acci;
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = v[i] + bi;
-            xch[0][gt][lane] = P::from_gi(P::to_gi(v));
-            xch[1][gt][lane] = acch;
+            KNS_WSTAMP(2);
+            if constexpr (P::kPrec == kBf16) {
+                xch[gt * 64 + lane] = P::from_gi(P::to_gi(v));
+                xch[(3 + gt) * 64 + lane] = acch;
+            } else {
+                f32x4 hb;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hb[i] = acch[i] + bh;
+                if (gt == 2) {
+                    xch[2 * 64 + lane] = v;
+                    xch[3 * 64 + lane] = hb;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hb[i] = v[i] + hb[i];
+                    xch[gt * 64 + lane] = hb;
+                }
+            }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B2 (not __syncthreads: the next m-tile's blocks stay in flight)
-        landed(obuf + cur * kBufBytes);
+        __syncthreads();  // B2
+        KNS_WSTAMP(3);
     }
-    __syncthreads();  // the gate wave's last B1
+    __syncthreads();  // role 3's last B1
 }
 
 // the state of a call's first frame in operand form: fp32 tiles [layer][m-tile][17][64][4] -> A-packed [layer][m-tile][NBH] blocks
@@ -514,7 +548,7 @@ __device__ __forceinline__ void gru_wave_head(const GruWaveItem &it, const int m
 template <class P>
 __global__ __launch_bounds__(256, 2) void gru_wave_kernel(GruWaveArgs w) {
     __shared__ __attribute__((aligned(16))) char obuf[2 * (2 * P::NBH + 3) * 1024];  // two operand buffers of [y | x | h] blocks
-    __shared__ f32x4 xch[2][3][64];
+    __shared__ f32x4 xch[(P::kPrec == kBf16 ? 6 : 4) * 64];
     // Workgroups are dealt to the eight XCDs round-robin by their linear index, and each XCD has its own L2: every workgroup of a
     // layer runs on ONE XCD (layer l on XCD l), so an XCD pulls one layer's weights per launch (1.8 MB in fp32) and serves its
     // workgroups from L2 -- dealt across the chip, every XCD's 4 MB L2 would see all eight layers' 14 MB and keep none.
@@ -531,11 +565,12 @@ __global__ __launch_bounds__(256, 2) void gru_wave_kernel(GruWaveArgs w) {
     const int m0 = grp * w.mgroup, m1 = m0 + w.mgroup < mtiles ? m0 + w.mgroup : mtiles;
     // (the gate wave sits on a different SIMD from workgroup to workgroup, so that the CU's four matrix pipes share the MFMA waves)
     const int role = __builtin_amdgcn_readfirstlane(((threadIdx.x >> 6) + slot) & 3);
+    const bool dbg = w.stamp && xcd == 3 && slot == 1;  // (KNS_TIMING builds)
     switch (__builtin_amdgcn_readfirstlane(it.g.nb0)) {
-        case 0: gru_wave_layer<P, 0>(it, u, m0, m1, role, obuf, xch); break;
-        case 1: gru_wave_layer<P, 1>(it, u, m0, m1, role, obuf, xch); break;
-        case 2: gru_wave_layer<P, 2>(it, u, m0, m1, role, obuf, xch); break;
-        default: gru_wave_layer<P, 3>(it, u, m0, m1, role, obuf, xch); break;
+        case 0: gru_wave_layer<P, 0>(it, u, m0, m1, role, obuf, xch, dbg); break;
+        case 1: gru_wave_layer<P, 1>(it, u, m0, m1, role, obuf, xch, dbg); break;
+        case 2: gru_wave_layer<P, 2>(it, u, m0, m1, role, obuf, xch, dbg); break;
+        default: gru_wave_layer<P, 3>(it, u, m0, m1, role, obuf, xch, dbg); break;
     }
 }
 

@@ -169,6 +169,7 @@ struct GruWaveArgs {
     int head_item[8];   // per XCD: a head item behind the layer's workgroups (-1: none)
     int layer_wgs;      // workgroups of a layer item = 17 x ceil(mtiles / mgroup)
     int mgroup;         // m-tiles per workgroup of a layer item
+    int stamp = 0;      // -DKNS_TIMING builds: this launch writes the s_memtime stamps
 };
 void launch_gru_wave(const GruWaveArgs &w, int precision, int mtiles, hipStream_t s);
 // the recurrent state [layers x mtiles][17 tiles] as A-packed operand blocks [layers x mtiles][NBH] (a wavefront call's frame 0)

@@ -375,7 +375,7 @@ import koala_amd
 from koala_amd.workload import synth_streams
 h = hashlib.sha256()
 for precision, B, T in (('bf16', 4096, 4), ('bf16', 4096, 1), ('bf16', 272, 3), ('bf16', 320, 5), ('fp32', 512, 2), ('bf16', 272, 1),
-                        ('fp32', 48, 1), ('bf16', 960, 1)):
+                        ('fp32', 48, 1), ('bf16', 960, 1), ('fp32', 48, 7), ('fp32', 250, 8), ('bf16', 512, 6)):  # (the last three: the wavefront route)
     x = np.tile(synth_streams(16, 2 * T, seed=9), ((B + 15) // 16, 1))[:B]
     kb = koala_amd.create_batch('key', B, T, precision, model_path=%(model)r, library_path=%(lib)r)
     for c in range(2):
@@ -411,11 +411,13 @@ def test_alternative_kernels_give_identical_pcm(random_model, random5_model):
                                'lib': DEV_LIB}
     for switch in ('', 'KOALA_AMD_GRU_STREAM', 'KOALA_AMD_GEMM_GENERIC',
                    'KOALA_AMD_GEMM_NO_WSR', 'KOALA_AMD_NO_SMALL', 'KOALA_AMD_NO_GRAPH', 'KOALA_AMD_STORE_SPECTRUM',
-                   'KOALA_AMD_DEBUG_TAPS', 'KOALA_AMD_NO_QUAD', 'KOALA_AMD_NO_HEAD_FUSE', 'KOALA_AMD_NO_STFT_FUSE'):  # (KOALA_AMD_NO_QUAD: one-frame calls of large
-        # batches through input GEMM + recurrent kernel instead of the one-step quad kernel, kns_gruq.hip)
+                   'KOALA_AMD_DEBUG_TAPS', 'KOALA_AMD_NO_QUAD', 'KOALA_AMD_NO_HEAD_FUSE', 'KOALA_AMD_NO_STFT_FUSE', 'KOALA_AMD_WAVE_MT=0',
+                   'KOALA_AMD_WAVE_MT=4096', 'KOALA_AMD_WAVE_GROUP=2'):  # (KOALA_AMD_NO_QUAD: one-frame calls of large
+        # batches through input GEMM + recurrent kernel instead of the one-step quad kernel, kns_gruq.hip; KOALA_AMD_WAVE_MT: multi-frame
+        # calls never / always as a wavefront over (layer, frame), kns_gru.hip gru_wave_kernel; _GROUP: its m-tiles per workgroup)
         env = dict(os.environ)
         if switch:
-            env[switch] = '1'
+            env[switch.split('=')[0]] = switch.split('=')[1] if '=' in switch else '1'
         out = subprocess.run([sys.executable, '-c', script], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, (switch, out.stderr[-2000:])
         digests[switch] = [ln for ln in out.stdout.splitlines() if ln.startswith('DIGEST')][-1]
@@ -621,15 +623,23 @@ def test_dispatch_boundaries(random_model, precision, B, T):
 
 
 @pytest.mark.parametrize('precision,B,T,route', [('bf16', 16, 1, 1), ('bf16', 944, 1, 1), ('bf16', 960, 1, 3), ('bf16', 976, 1, 1),
-                                                 ('bf16', 3072, 1, 3), ('bf16', 3088, 1, 0), ('bf16', 4096, 1, 3), ('bf16', 64, 4, 0),
+                                                 ('bf16', 3072, 1, 3), ('bf16', 3088, 1, 0), ('bf16', 4096, 1, 3), ('bf16', 64, 4, 4),
+                                                 ('bf16', 512, 2, 4), ('bf16', 528, 2, 0),
                                                  ('bf16', 4096, 4, 0), ('fp32', 256, 1, 1), ('fp32', 4096, 1, 1), ('fp32', 4112, 1, 0),
-                                                 ('fp32', 256, 4, 2), ('fp32', 3072, 2, 2), ('fp32', 3088, 2, 0)])
+                                                 ('fp32', 64, 2, 4), ('fp32', 256, 4, 2), ('fp32', 256, 6, 4), ('fp32', 512, 8, 2), ('fp32', 512, 12, 4),
+                                                 ('fp32', 2048, 24, 4), ('fp32', 2064, 24, 2), ('fp32', 3072, 2, 2), ('fp32', 3088, 2, 0)])
 def test_dispatch_routes(random_model, precision, B, T, route):
     """The dispatch table at the head of Engine::run_device (kns_engine.cpp), row by row: the developer build says which kernel
-    family the last call took (0 chunked, 1 low-latency layer kernel, 2 the same frame by frame, 3 one-step quad kernel) and what
+    family the last call took (0 chunked, 1 low-latency layer kernel, 2 the same frame by frame, 3 one-step quad kernel, 4 wavefront over
+    (layer, frame)) and what
     rode inside other launches."""
+    torch = pytest.importorskip('torch')
     kb = koala_amd.create_batch('key', B, T, precision, model_path=random_model, library_path=DEV_LIB)
-    kb.process(synth_streams(B, T, seed=1))
+    x = torch.from_numpy(synth_streams(B, T, seed=1)).cuda()  # (device pointers: a large host call would be cut into sub-chunks)
+    y = torch.zeros_like(x)
+    torch.cuda.synchronize()
+    kb.process_device(T, x.data_ptr(), y.data_ptr())
+    kb.synchronize()
     got = kb.debug_read('route', T)
     kb.delete()
     assert int(got[0]) == route, got.tolist()

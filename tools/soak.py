@@ -22,7 +22,7 @@ def main():
     rng = np.random.default_rng(7)
     cases = [('random', 'bf16', 4096, 8, 60), ('random', 'fp32', 1000, 8, 40), ('random', 'bf16', 300, 16, 80), ('random5', 'bf16', 1030, 6, 60),
              ('random5', 'fp32', 77, 9, 60), ('adaptive', 'bf16', 2048, 4, 40), ('adaptive', 'fp32', 256, 32, 12), ('random', 'bf16', 17, 5, 200),
-             ('random', 'fp32', 16, 3, 200)]
+             ('random', 'fp32', 16, 3, 200), ('random', 'fp32', 200, 12, 60), ('random5', 'bf16', 100, 9, 60), ('random', 'bf16', 500, 40, 30)]
     bad = 0
     for kind, precision, B, Tmax, calls in cases:
         calls = max(4, int(calls * scale))
