@@ -1,4 +1,4 @@
-"""Developer tool: s_memtime stamps (100 MHz ticks) inside gru_wave_kernel -- the workgroup in slot 1 of XCD 3 (layer 3), second
+"""Developer tool: s_memtime stamps (shader-clock cycles) inside gru_wave_kernel -- the workgroup in slot 1 of XCD 3 (layer 3), second
 m-tile of its group, in a mid-call launch (needs a -DKNS_TIMING -DKNS_DEV build, made here).
   python tools/wave_timing.py [streams]       WAVE_PREC=fp32|bf16, KOALA_AMD_WAVE_GROUP=<m-tiles per workgroup>"""
 import ctypes as C, os, subprocess, sys
@@ -28,8 +28,8 @@ buf = (C.c_ulonglong * 128)()
 l.pv_koala_debug_timing(buf)
 t = np.array(buf[:128], dtype=np.int64).reshape(8, 16)
 base = t[:4, 0].min()
-print('%s %d streams, group %s: stamps of roles 0-2 (MFMA: top, after the barrier, MFMAs done, exchange written) and 3 '
-      '(top, after the barrier, requests issued + exchange taken, gates done, next blocks landed); 10 ns ticks from the earliest' % (prec, B, os.environ.get('KOALA_AMD_WAVE_GROUP', 'auto')))
+print('%s %d streams, group %s: stamps of roles 0-2 (MFMA waves: top of the m-tile, after B1, MFMAs done, after B2) and 3 '
+      '(top, after B1, next requests issued + gates of the m-tile before done, after B2, exchange taken + requested blocks landed); cycles from the earliest' % (prec, B, os.environ.get('KOALA_AMD_WAVE_GROUP', 'auto')))
 for w in range(4):
     n = 4 if w < 3 else 5
     print('role %d:' % w, ' '.join('%6d' % (v - base) for v in t[w, :n]), ' | deltas:', ' '.join('%5d' % d for d in np.diff(t[w, :n])))
