@@ -275,6 +275,7 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     dev_steps_mt_ = dev_int("KOALA_AMD_STEPS_MT", 192);
     dev_wave_mt_ = dev_int("KOALA_AMD_WAVE_MT", -1);  // -1: the measured limits; 0: never
     dev_wave_group_ = dev_int("KOALA_AMD_WAVE_GROUP", 0);
+    dev_wave_parts_ = dev_int("KOALA_AMD_WAVE_PARTS", 1);  // 0: a layer never takes more than one XCD
     // One-frame calls of large batches: a GRU layer as ONE launch fused over CU quads (kns_gruq.hip, gru_quad1_kernel), bit-identical
     // to the two-kernel form -- a CU pulls a quarter of W_ih and W_hh (300 KiB) per layer instead of a half of one and all of the
     // other (~740 KiB): 128 against 222 us per 4096-stream frame step.  (The multi-frame form of that decomposition measured slower
@@ -640,16 +641,16 @@ bool Engine::reset(const uint8_t *host_mask, std::string *err) {
 //   | bf16          | 1        | >= 60 and mtb % 4 == 0                | kRouteQuad1: gru_quad1_kernel, one launch per layer; stage    |
 //   |               |          |                                       |   inputs wider than 2 k-blocks: input GEMM + recurrent kernel |
 //   | bf16          | 1        | > 192 and mtb % 4 != 0                | kRouteChunked                                                 |
-//   | bf16          | > 1      | <= 32                                 | kRouteWave: gru_wave_kernel, T + 10 launches: the (stage,     |
+//   | bf16          | > 1      | <= 32 (<= 64 up to T = 4)             | kRouteWave: gru_wave_kernel, T + 10 launches: the (stage,     |
 //   |               |          |                                       |   frame) items of one anti-diagonal side by side, one layer   |
 //   |               |          |                                       |   per XCD, narrow heads as items of their own                 |
-//   | bf16          | > 1      | > 32                                  | kRouteChunked: gemm_ws2 (m-tiles in multiples of 256 x stage; |
+//   | bf16          | > 1      | otherwise                             | kRouteChunked: gemm_ws2 (m-tiles in multiples of 256 x stage; |
 //   |               |          |                                       |   the rest through gemm_kernel) + gru_resident8_kernel        |
 //   | fp32          | 1        | <= 256                                | kRouteSmall                                                   |
 //   | fp32          | 1        | > 256                                 | kRouteChunked: gemm_kernel + gru_kernel<PF32, 8>              |
-//   | fp32          | > 1      | <= 4; <= 16 from T = 6, <= 32 from 12,| kRouteWave                                                   |
-//   |               |          |   <= 128 from 24                      |                                                              |
-//   | fp32          | > 1      | otherwise <= 192                      | kRouteSmallSteps: gru_small_kernel frame by frame (T launches |
+//   | fp32          | > 1      | <= 256                                | kRouteWave                                                   |
+//   | fp32          | > 1      | <= 192, wavefront off (developer      | kRouteSmallSteps: gru_small_kernel frame by frame (T launches |
+//   |               |          |   switch, debug taps)                 |                                                              |
 //   |               |          |                                       |   per layer; the chunked recurrence would occupy mtb CUs)     |
 //   | fp32          | > 1      | > 192                                 | kRouteChunked                                                 |
 //
@@ -867,12 +868,11 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         }
         return it;
     };
-    // Where it wins (measured against the other routes, tools/wave_check.py): bf16 up to 512 streams at any T > 1 (32 frames: 32.4
-    // against 24.1 M frames/s at 512 streams, 38.8 against 43.3 at 1 024 -- there the chunked kernels' resident weights win); fp32 --
-    // whose launches are MFMA-bound, so the ten launches that fill and drain the pipeline cost more -- from T frames on that grow with
-    // the batch (256 streams: 0.45 against 0.39 ms at T = 4, 0.57 against 0.69 at T = 8; 2 048 streams x 32: 7.2 against 8.7 ms;
-    // 4 096 x 32: 13.6 against 13.4)
-    const bool wave_wins = prec_ == kBf16 ? mtb <= 32 : (mtb <= 4 || (mtb <= 16 && T >= 6) || (mtb <= 32 && T >= 12) || (mtb <= 128 && T >= 24));
+    // Where it wins (measured against the other routes, tools/wave_check.py, profiles/r04_wavefront.txt): fp32 at every size measured
+    // (2 frames x 256 streams: 0.19 against 0.23 ms; 32 x 256: 1.13 against 2.52; 32 x 4 096: 11.4 against 13.5); bf16 up to 512 streams
+    // (32 frames: 0.49 against 0.68 ms; 768 streams: equal; beyond, the chunked kernels' resident weights win -- 1 024 x 32: 0.81
+    // against 0.76 ms -- except in calls of 2-4 frames)
+    const bool wave_wins = prec_ == kBf16 ? (mtb <= 32 || (mtb <= 64 && T <= 4)) : mtb <= 256;
     bool wave = T > 1 && (dev_wave_mt_ >= 0 ? mtb <= dev_wave_mt_ : wave_wins) && !no_small_ && !debug_taps_ && (only < 0 || only == kClsGru);
     for (int s = 0; wave && s < kStages - 1; ++s)
         wave = sd_[s + 1].ypad ? sd_[s].head_dim <= 16 : (nby_[s] >= 1 && nby_[s] <= 3 && sd_[s].head_tiles == pi_.npb * nby_[s]);
@@ -942,15 +942,26 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
             w.stamp = k == T / 2 + 5;
 #endif
             w.layer_wgs = kUnitTiles * ((mtb + mgroup - 1) / mgroup);
-            for (int x = 0; x < 8; ++x) w.layer_item[x] = w.head_item[x] = -1;
-            int n = 0;
-            for (int i = k < T ? 0 : k - T + 1; i <= k && i < kWaveItems; ++i) {
+            for (int x = 0; x < 8; ++x) w.layer_item[x] = w.head_item[x] = -1, w.layer_part[x] = 0;
+            int n = 0, layers = 0;
+            const int i0 = k < T ? 0 : k - T + 1;
+            for (int i = i0; i <= k && i < kWaveItems; ++i) layers += i % 3 != 2;
+            // one layer per XCD; four or fewer layers (the pipeline filling or draining) take 2, 4 or 8 XCDs each
+            w.parts = dev_wave_parts_ ? (layers <= 1 ? 8 : layers <= 2 ? 4 : layers <= 4 ? 2 : 1) : 1;
+            w.xcd_wgs = (w.layer_wgs + w.parts - 1) / w.parts;
+            int seen = 0;
+            for (int i = i0; i <= k && i < kWaveItems; ++i) {
                 w.item[n] = wave_item(i, k - i);
-                // layer l on XCD l; the head of stage s beside that stage's layer B
-                if (i % 3 == 2)
-                    w.head_item[2 * (i / 3) + 1] = n;
-                else
-                    w.layer_item[2 * (i / 3) + i % 3] = n;
+                if (i % 3 == 2) {  // the head of stage s: beside a layer's workgroups, on the XCD(s) of the layer before it in this launch
+                    w.head_item[w.parts == 1 ? 2 * (i / 3) + 1 : (seen ? seen - 1 : 0) * w.parts] = n;
+                } else {
+                    for (int q = 0; q < w.parts; ++q) {
+                        const int x = w.parts == 1 ? 2 * (i / 3) + i % 3 : seen * w.parts + q;  // (all eight in flight: layer l on XCD l)
+                        w.layer_item[x] = n;
+                        w.layer_part[x] = q;
+                    }
+                    ++seen;
+                }
                 ++n;
             }
             tick(kClsGru);

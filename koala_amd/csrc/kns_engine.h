@@ -110,7 +110,7 @@ private:
     hipGraphExec_t frame_graph_[8] = {};  // one per combination of the hidden-state / history / tail ping-pong indices
     bool use_graph_ = true, no_small_ = false, no_zero_copy_ = false, no_recompute_ = false, debug_taps_ = false;
     // developer switches (all read once in init() through dev_env(): compiled out of the product library)
-    int dev_variant_ = 0, dev_only_class_ = -1, dev_analysis_seg_ = 0, dev_synth_seg_ = 0, dev_small_mt_ = 0, dev_steps_mt_ = 192, dev_wave_mt_ = -1, dev_wave_group_ = 0;
+    int dev_variant_ = 0, dev_only_class_ = -1, dev_analysis_seg_ = 0, dev_synth_seg_ = 0, dev_small_mt_ = 0, dev_steps_mt_ = 192, dev_wave_mt_ = -1, dev_wave_group_ = 0, dev_wave_parts_ = 1;
     // one-frame calls: GRU layers fused over CU quads (kns_gruq.hip); narrow heads / front-end / mask head inside their consumers
     bool use_quad_ = true;
     int quad_nb0_max_ = 2;

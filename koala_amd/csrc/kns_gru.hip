@@ -552,13 +552,16 @@ __global__ __launch_bounds__(256, 2) void gru_wave_kernel(GruWaveArgs w) {
     // Workgroups are dealt to the eight XCDs round-robin by their linear index, and each XCD has its own L2: every workgroup of a
     // layer runs on ONE XCD (layer l on XCD l), so an XCD pulls one layer's weights per launch (1.8 MB in fp32) and serves its
     // workgroups from L2 -- dealt across the chip, every XCD's 4 MB L2 would see all eight layers' 14 MB and keep none.
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    // (while the pipeline fills and drains fewer than eight layers are in a launch: four or fewer share the XCDs 2, 4 or 8 to a layer,
+    // XCD x taking every parts-th workgroup of its layer)
+    const int xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
     const int li = w.layer_item[xcd], hi = w.head_item[xcd];
-    if (slot >= w.layer_wgs) {  // a head: one workgroup per m-tile
-        if (hi >= 0 && slot - w.layer_wgs < w.item[hi].g.mtiles) gru_wave_head<P>(w.item[hi], slot - w.layer_wgs);
+    if (xslot >= w.xcd_wgs) {  // a head: one workgroup per m-tile
+        if (hi >= 0 && xslot - w.xcd_wgs < w.item[hi].g.mtiles) gru_wave_head<P>(w.item[hi], xslot - w.xcd_wgs);
         return;
     }
-    if (li < 0) return;
+    const int slot = xslot * w.parts + w.layer_part[xcd];
+    if (li < 0 || slot >= w.layer_wgs) return;
     const GruWaveItem &it = w.item[li];
     const int mtiles = it.g.mtiles;
     const int u = slot % kUnitTiles, grp = slot / kUnitTiles;
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void gru_wave_kernel(GruWaveArgs w) {
 void launch_gru_wave(const GruWaveArgs &w, int precision, int mtiles, hipStream_t s) {
     bool heads = false;
     for (int x = 0; x < 8; ++x) heads = heads || w.head_item[x] >= 0;
-    dim3 grid(8 * (w.layer_wgs + (heads ? mtiles : 0)));
+    dim3 grid(8 * (w.xcd_wgs + (heads ? mtiles : 0)));
     if (precision == kBf16)
         hipLaunchKernelGGL(gru_wave_kernel<PBF16>, grid, dim3(256), 0, s, w);
     else

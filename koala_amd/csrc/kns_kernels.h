@@ -167,7 +167,10 @@ struct GruWaveArgs {
     GruWaveItem item[kWaveItems];
     int layer_item[8];  // per XCD: the layer item its workgroups run (-1: none in this launch)
     int head_item[8];   // per XCD: a head item behind the layer's workgroups (-1: none)
+    int layer_part[8];  // per XCD: which of the `parts` shares of its layer's workgroups it runs
+    int parts;          // XCDs per layer in this launch: 1, 2, 4 or 8
     int layer_wgs;      // workgroups of a layer item = 17 x ceil(mtiles / mgroup)
+    int xcd_wgs;        // layer workgroups per XCD = ceil(layer_wgs / parts)
     int mgroup;         // m-tiles per workgroup of a layer item
     int stamp = 0;      // -DKNS_TIMING builds: this launch writes the s_memtime stamps
 };

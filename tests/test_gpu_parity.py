@@ -428,7 +428,7 @@ def test_alternative_kernels_give_identical_pcm(random_model, random5_model):
                                                     ('bf16', 4096, 4, 10), ('bf16', 4100, 3, 8), ('fp32', 4096, 2, 6)])
 def test_random_call_sequences_keep_the_stream_state_straight(random_model, precision, B, Tmax, calls):
     """A soak over the state bookkeeping (history / overlap-add / hidden-state ping-pong buffers, the single-frame graph,
-    the frame-by-frame fp32 path, masked resets): random chunk lengths, host and device pointers, random per-stream resets --
+    the wavefront route of multi-frame calls, masked resets): random chunk lengths, host and device pointers, random per-stream resets --
     the engine must track the oracle, which is driven through the same sequence, call by call."""
     torch = pytest.importorskip('torch')
     rng = np.random.default_rng(42)
@@ -466,8 +466,8 @@ def test_random_call_sequences_keep_the_stream_state_straight(random_model, prec
                                            ('bf16', 1040, 9)])
 def test_long_chunks_of_small_and_odd_batches(random_model, precision, B, T):
     """Odd frame counts and small or ragged batches in ONE call: the synthesis kernel's time segments (each replays a frame
-    to rebuild its overlap-add tail, and they shrink with the stream count), the frame-by-frame fp32 layers and the
-    fallback GEMMs all see shapes the throughput configuration never produces."""
+    to rebuild its overlap-add tail, and they shrink with the stream count), the wavefront over (layer, frame) with ragged
+    m-tile groups and the fallback GEMMs all see shapes the throughput configuration never produces."""
     x = synth_streams(B, T, seed=77)
     kb = koala_amd.create_batch('key', B, T, precision, model_path=random_model)
     y = kb.process(x)
@@ -587,7 +587,7 @@ def test_host_calls_on_a_caller_stream(random_model):
 @pytest.mark.parametrize('T,calls', [(1, 3), (32, 2)])
 def test_baseline_config1_b256_fp32_at_its_stated_size(random_model, T, calls):
     """BASELINE configs[1] exactly: 256 streams, fp32 mask network -- one frame per call (16 m-tiles: the single-launch
-    low-latency layers) and 32 frames per call (the frame-by-frame fp32 layers).  Every stream against the oracle."""
+    low-latency layers) and 32 frames per call (the wavefront route: kns_gru.hip, gru_wave_kernel).  Every stream against the oracle."""
     B = 256
     x = synth_streams(B, T * calls, seed=256)
     kb = koala_amd.create_batch('key', B, T, 'fp32', model_path=random_model)
@@ -601,13 +601,13 @@ def test_baseline_config1_b256_fp32_at_its_stated_size(random_model, T, calls):
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
 @pytest.mark.parametrize('B,T', [(256, 1), (272, 1), (944, 1), (960, 1), (976, 1), (1792, 1), (3072, 1), (3088, 1), (4090, 1), (4096, 1), (4112, 1), (8192, 1), (3072, 2),
-                                 (3088, 2)])
+                                 (3088, 2), (512, 5), (528, 5), (1024, 3), (1040, 3), (4112, 2)])
 def test_dispatch_boundaries(random_model, precision, B, T):
     """The engine switches kernel families between one-frame calls below and above 192 m-tiles (bf16) / 256 m-tiles (fp32)
     (low-latency layer kernel vs input GEMM + recurrent kernel; 16 m-tiles was the edge in round 1), in bf16 already at
-    59 -> 60 m-tiles when the m-tiles make whole quads (one-step fused quad kernel; 61 m-tiles do not), and at 192 -> 193
-    m-tiles for several frames in fp32 (frame-by-frame layers vs chunked recurrence), kns_engine.cpp run_device().  Both
-    sides of every edge, two calls each, every stream against the oracle."""
+    59 -> 60 m-tiles when the m-tiles make whole quads (one-step fused quad kernel; 61 m-tiles do not); calls of several frames
+    change between the wavefront route and the chunked kernels at 32 / 64 m-tiles (bf16) and 256 (fp32), kns_engine.cpp
+    run_device().  Both sides of every edge, two calls each, every stream against the oracle."""
     base = synth_streams(128, 2 * T, seed=B)
     x = np.tile(base, ((B + 127) // 128, 1))[:B]
     kb = koala_amd.create_batch('key', B, T, precision, model_path=random_model)
@@ -624,10 +624,9 @@ def test_dispatch_boundaries(random_model, precision, B, T):
 
 @pytest.mark.parametrize('precision,B,T,route', [('bf16', 16, 1, 1), ('bf16', 944, 1, 1), ('bf16', 960, 1, 3), ('bf16', 976, 1, 1),
                                                  ('bf16', 3072, 1, 3), ('bf16', 3088, 1, 0), ('bf16', 4096, 1, 3), ('bf16', 64, 4, 4),
-                                                 ('bf16', 512, 2, 4), ('bf16', 528, 2, 0),
+                                                 ('bf16', 512, 8, 4), ('bf16', 528, 8, 0), ('bf16', 1024, 4, 4), ('bf16', 1024, 5, 0), ('bf16', 1040, 2, 0),
                                                  ('bf16', 4096, 4, 0), ('fp32', 256, 1, 1), ('fp32', 4096, 1, 1), ('fp32', 4112, 1, 0),
-                                                 ('fp32', 64, 2, 4), ('fp32', 256, 4, 2), ('fp32', 256, 6, 4), ('fp32', 512, 8, 2), ('fp32', 512, 12, 4),
-                                                 ('fp32', 2048, 24, 4), ('fp32', 2064, 24, 2), ('fp32', 3072, 2, 2), ('fp32', 3088, 2, 0)])
+                                                 ('fp32', 64, 2, 4), ('fp32', 256, 32, 4), ('fp32', 4096, 2, 4), ('fp32', 4112, 2, 0)])
 def test_dispatch_routes(random_model, precision, B, T, route):
     """The dispatch table at the head of Engine::run_device (kns_engine.cpp), row by row: the developer build says which kernel
     family the last call took (0 chunked, 1 low-latency layer kernel, 2 the same frame by frame, 3 one-step quad kernel, 4 wavefront over
