@@ -8,10 +8,10 @@ echo "# layer-by-layer routes (fp32: gru_small_kernel frame by frame / chunked k
 echo "# tools/wave_check.py, one MI355X box, device-resident PCM, 50 calls timed after 5; 'max |diff|' = the two routes' PCM over"
 echo "# three consecutive calls (state carried).  Commit $(git rev-parse --short HEAD 2>/dev/null || echo '?')."
 echo
-echo "## 32 frames per call, wavefront forced at every size (the engine's own limits: bf16 up to 512 streams, fp32 up to 2 048 at 32 frames)"
+echo "## 32 frames per call, wavefront forced at every size (the engine takes it in fp32 at every size up to 4 096 streams, in bf16 up to 512)"
 WAVE_T=32 run 16 64 128 256 512 1024 2048 4096
 echo
-echo "## 256 and 512 streams, frames per call swept (wavefront forced; the engine takes it in bf16 from 2 frames, in fp32 from 6 / 12)"
+echo "## 256 and 512 streams, frames per call swept"
 for T in 2 4 8 16 64; do WAVE_T=$T run 256 512; done
 echo
 echo "## 256 streams x 32 frames, m-tiles per workgroup (KOALA_AMD_WAVE_GROUP; the engine's choice at 256 streams: 3)"
