@@ -630,6 +630,127 @@ bool Engine::reset(const uint8_t *host_mask, std::string *err) {
     return true;
 }
 
+// the arguments of one GRU layer of ONE frame (frame t of a call) for the low-latency layer kernel and the wavefront's items
+GruSmallArgs Engine::small_args(int mtb, const void *a0, int nb0, const void *a1, const void *wih, const float *bih, const void *whh,
+                                const float *bhh, int layer, void *hseq, int t, const StageDev *head) const {
+    GruSmallArgs g;
+    const size_t frame = (size_t) t * mtb * 1024;  // bytes of one k-block column of A per frame
+    if (head) {  // the narrow head of the stage before, inside this launch
+        g.yh = (const char *) d_hseq_b_ + frame * nbh_;
+        g.yw = head->w_head;
+        g.yb = head->b_head;
+        g.yvalid = head->head_dim;
+    }
+    g.a0 = a0 ? (const char *) a0 + frame * nb0 : nullptr;
+    g.a1 = (const char *) a1 + frame * nbh_;
+    g.wih = wih;
+    g.bih = bih;
+    g.whh = whh;
+    g.bhh = bhh;
+    g.hstate_in = d_hstate_[(hs_cur_ + t) & 1] + (size_t) layer * mtb * kUnitTiles * 256;
+    g.hstate_out = d_hstate_[(hs_cur_ + t + 1) & 1] + (size_t) layer * mtb * kUnitTiles * 256;
+    g.hseq = (char *) hseq + frame * nbh_;
+    g.nb0 = nb0;
+    g.mtiles = mtb;
+    g.precision = prec_;
+    return g;
+}
+
+// ---- calls of several frames as a WAVEFRONT over (pipeline stage, frame): the stages are the eight GRU layers with the three narrow
+// heads between them; stage i of frame t needs stage i - 1 of frame t and (a layer) its own frame t - 1, so launch k runs the items with
+// i + t = k side by side (kns_gru.hip, gru_wave_kernel) -- T + 10 launches of up to 8 x 17 x groups workgroups instead of 8 T launches of
+// 17 x mtb (kRouteSmallSteps) or of mtb (the chunked recurrent kernels).  The per-frame slots of the two hidden-sequence buffers, of the
+// y operands and of the features' padding are reused stage after stage exactly as in the layer-by-layer order: within a frame the stages
+// still run one after the other.
+GruWaveItem Engine::wave_item(int i, int t, int mtb) const {  // stage i (layers 3 s, 3 s + 1; head 3 s + 2) of frame t
+    const int s = i / 3, r = i % 3;
+    const StageDev &d = sd_[s];
+    const size_t frame = (size_t) t * mtb * 1024;
+    char *feat_call = (char *) d_feat_ + (size_t) (taps_ - 1) * feat_frame_bytes_;
+    GruWaveItem it;
+    if (r == 2) {  // the head of stage s
+        it.g.yh = (const char *) d_hseq_b_ + frame * nbh_;
+        it.g.yw = d.w_head;
+        it.g.yb = d.b_head;
+        it.g.yvalid = d.head_dim;
+        it.g.mtiles = mtb;
+        it.g.precision = prec_;
+        if (sd_[s + 1].ypad) {  // into columns 257 ... of the features (k = 1 ... of their block 8)
+            it.chains = 1;
+            it.pad = 1;
+            it.yout = feat_call + frame * nbf_;
+            it.y_nb = nbf_;
+            it.y_blk = kBins / pi_.kb;
+            it.y_kk0 = kBins % pi_.kb;
+        } else {
+            it.chains = d.head_tiles;
+            it.yout = (char *) d_y_[s] + frame * nby_[s];
+            it.y_nb = nby_[s];
+        }
+        return it;
+    }
+    // h_{t-1} in operand form: the layer's hidden-sequence slot of the frame before, or the converted state (d_hprev_) for frame 0
+    const void *hseq = r ? d_hseq_b_ : d_hseq_a_;
+    it.hprev = t ? (const char *) hseq + (frame - (size_t) mtb * 1024) * nbh_ : (const char *) d_hprev_ + (size_t) (2 * s + r) * mtb * nbh_ * 1024;
+    if (r == 1) {
+        it.g = small_args(mtb, nullptr, 0, d_hseq_a_, d.w_ih_b, d.b_ih_b, d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_, t, nullptr);
+    } else {
+        const bool y = s && !d.ypad;
+        it.g = small_args(mtb, y ? d_y_[s - 1] : nullptr, y ? nby_[s - 1] : 0, fold_ ? (const void *) feat_call : (const void *) d_e_, d.w_ih_a,
+                          d.b_ih_a, d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_, t, nullptr);
+    }
+    return it;
+}
+
+bool Engine::wave_fits() const {  // every head either goes into the features' padding or is a y operand of 1-3 k-blocks
+    for (int s = 0; s < kStages - 1; ++s)
+        if (!(sd_[s + 1].ypad ? sd_[s].head_dim <= 16 : (nby_[s] >= 1 && nby_[s] <= 3 && sd_[s].head_tiles == pi_.npb * nby_[s]))) return false;
+    return true;
+}
+
+void Engine::run_wave(int T, int mtb) {
+    // m-tiles per workgroup (an XCD holds 64 workgroups at a time, a layer has 17 per group; measured best: 1 up to 64 streams,
+    // 3 up to 256, 6 up to 512, 8 beyond -- short groups balance the CUs, long ones pull the weights less often)
+    int mgroup = mtb <= 4 ? 1 : mtb <= 16 ? 3 : mtb <= 32 ? 6 : 8;
+    if (dev_wave_group_ > 0) mgroup = dev_wave_group_;
+    tick(kClsGru);
+    launch_gru_wave_prev(d_hstate_[hs_cur_], d_hprev_, kGruLayers * mtb, prec_, stream_);
+    tock(kClsGru);
+    for (int k = 0; k < T + kWaveItems - 1; ++k) {
+        GruWaveArgs w;
+        w.mgroup = mgroup;
+#ifdef KNS_TIMING
+        w.stamp = k == T / 2 + 5;
+#endif
+        w.layer_wgs = kUnitTiles * ((mtb + mgroup - 1) / mgroup);
+        for (int x = 0; x < 8; ++x) w.layer_item[x] = w.head_item[x] = -1, w.layer_part[x] = 0;
+        int n = 0, layers = 0;
+        const int i0 = k < T ? 0 : k - T + 1;
+        for (int i = i0; i <= k && i < kWaveItems; ++i) layers += i % 3 != 2;
+        // one layer per XCD; four or fewer layers (the pipeline filling or draining) take 2, 4 or 8 XCDs each
+        w.parts = dev_wave_parts_ ? (layers <= 1 ? 8 : layers <= 2 ? 4 : layers <= 4 ? 2 : 1) : 1;
+        w.xcd_wgs = (w.layer_wgs + w.parts - 1) / w.parts;
+        int seen = 0;
+        for (int i = i0; i <= k && i < kWaveItems; ++i) {
+            w.item[n] = wave_item(i, k - i, mtb);
+            if (i % 3 == 2) {  // the head of stage s: beside a layer's workgroups, on the XCD(s) of the layer before it in this launch
+                w.head_item[w.parts == 1 ? 2 * (i / 3) + 1 : (seen ? seen - 1 : 0) * w.parts] = n;
+            } else {
+                for (int q = 0; q < w.parts; ++q) {
+                    const int x = w.parts == 1 ? 2 * (i / 3) + i % 3 : seen * w.parts + q;  // (all eight in flight: layer l on XCD l)
+                    w.layer_item[x] = n;
+                    w.layer_part[x] = q;
+                }
+                ++seen;
+            }
+            ++n;
+        }
+        tick(kClsGru);
+        launch_gru_wave(w, prec_, mtb, stream_);
+        tock(kClsGru);
+    }
+}
+
 // ---- dispatch: which kernel family a call takes (mtb = m-tiles of 16 streams = ceil(B / 16); edges measured on MI355X, each
 // tested from both sides by tests/test_gpu_parity.py::test_dispatch_boundaries; the developer build reports the route of the
 // last call through debug tap 6, tests/test_gpu_parity.py::test_dispatch_routes)
@@ -795,87 +916,19 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     const int steps_mt = dev_steps_mt_;
     // (fp32 only: the bf16 recurrent kernel keeps its weights on chip and is faster than 8 us per frame and layer even
     // with 16 workgroups -- 11.3 vs 5.2 M frames/s at 256 streams; the fp32 one streams them: 1.2 vs 2.8 M)
-    auto small_args = [&](const void *a0, int nb0, const void *a1, const void *wih, const float *bih, const void *whh,
-                          const float *bhh, int layer, void *hseq, int t, const StageDev *head) {
-        GruSmallArgs g;
-        const size_t frame = (size_t) t * mtb * 1024;  // bytes of one k-block column of A per frame
-        if (head) {  // the narrow head of the stage before, inside this launch
-            g.yh = (const char *) d_hseq_b_ + frame * nbh_;
-            g.yw = head->w_head;
-            g.yb = head->b_head;
-            g.yvalid = head->head_dim;
-        }
-        g.a0 = a0 ? (const char *) a0 + frame * nb0 : nullptr;
-        g.a1 = (const char *) a1 + frame * nbh_;
-        g.wih = wih;
-        g.bih = bih;
-        g.whh = whh;
-        g.bhh = bhh;
-        g.hstate_in = d_hstate_[(hs_cur_ + t) & 1] + (size_t) layer * mtb * kUnitTiles * 256;
-        g.hstate_out = d_hstate_[(hs_cur_ + t + 1) & 1] + (size_t) layer * mtb * kUnitTiles * 256;
-        g.hseq = (char *) hseq + frame * nbh_;
-        g.nb0 = nb0;
-        g.mtiles = mtb;
-        g.precision = prec_;
-        return g;
-    };
     auto gru_small = [&](const void *a0, int nb0, const void *a1, const void *wih, const float *bih, const void *whh,
                          const float *bhh, int layer, void *hseq, int t = 0, const StageDev *head = nullptr) {
-        const GruSmallArgs g = small_args(a0, nb0, a1, wih, bih, whh, bhh, layer, hseq, t, head);
+        const GruSmallArgs g = small_args(mtb, a0, nb0, a1, wih, bih, whh, bhh, layer, hseq, t, head);
         tick(kClsGru);
         launch_gru_small(g, stream_);
         tock(kClsGru);
-    };
-    // Multi-frame calls of few streams, as a WAVEFRONT over (pipeline stage, frame): the stages are the eight GRU layers with the
-    // three narrow heads between them; stage i of frame t needs stage i - 1 of frame t and (a layer) its own frame t - 1, so launch k
-    // runs the items with i + t = k side by side (kns_gru.hip, gru_wave_kernel) -- T + 10 launches of up to 8 x 17 x groups workgroups
-    // instead of 8 T launches of 17 x mtb (kRouteSmallSteps) or of mtb (the chunked recurrent kernels).  The per-frame slots of the two
-    // hidden-sequence buffers, of the y operands and of the features' padding are reused stage after stage exactly as in the
-    // layer-by-layer order: within a frame the stages still run one after the other.
-    char *feat_call = (char *) d_feat_ + (size_t) (taps_ - 1) * feat_frame_bytes_;
-    auto wave_item = [&](int i, int t) {
-        const int s = i / 3, r = i % 3;
-        const StageDev &d = sd_[s];
-        const size_t frame = (size_t) t * mtb * 1024;
-        GruWaveItem it;
-        if (r == 2) {  // the head of stage s
-            it.g.yh = (const char *) d_hseq_b_ + frame * nbh_;
-            it.g.yw = d.w_head;
-            it.g.yb = d.b_head;
-            it.g.yvalid = d.head_dim;
-            it.g.mtiles = mtb;
-            it.g.precision = prec_;
-            if (sd_[s + 1].ypad) {
-                it.chains = 1;
-                it.pad = 1;
-                it.yout = feat_call + frame * nbf_;
-                it.y_nb = nbf_;
-                it.y_blk = kBins / pi_.kb;
-                it.y_kk0 = kBins % pi_.kb;
-            } else {
-                it.chains = d.head_tiles;
-                it.yout = (char *) d_y_[s] + frame * nby_[s];
-                it.y_nb = nby_[s];
-            }
-        } else if (r == 1) {
-            it.g = small_args(nullptr, 0, d_hseq_a_, d.w_ih_b, d.b_ih_b, d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_, t, nullptr);
-            it.hprev = t ? (const char *) d_hseq_b_ + (frame - (size_t) mtb * 1024) * nbh_ : (const char *) d_hprev_ + (size_t) (2 * s + 1) * mtb * nbh_ * 1024;
-        } else {
-            it.hprev = t ? (const char *) d_hseq_a_ + (frame - (size_t) mtb * 1024) * nbh_ : (const char *) d_hprev_ + (size_t) (2 * s) * mtb * nbh_ * 1024;
-            const bool y = s && !d.ypad;
-            it.g = small_args(y ? d_y_[s - 1] : nullptr, y ? nby_[s - 1] : 0, fold_ ? (const void *) feat_call : (const void *) d_e_, d.w_ih_a,
-                              d.b_ih_a, d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_, t, nullptr);
-        }
-        return it;
     };
     // Where it wins (measured against the other routes, tools/wave_check.py, profiles/r04_wavefront.txt): fp32 at every size measured
     // (2 frames x 256 streams: 0.19 against 0.23 ms; 32 x 256: 1.13 against 2.52; 32 x 4 096: 11.4 against 13.5); bf16 up to 512 streams
     // (32 frames: 0.49 against 0.68 ms; 768 streams: equal; beyond, the chunked kernels' resident weights win -- 1 024 x 32: 0.81
     // against 0.76 ms -- except in calls of 2-4 frames)
     const bool wave_wins = prec_ == kBf16 ? (mtb <= 32 || (mtb <= 64 && T <= 4)) : mtb <= 256;
-    bool wave = T > 1 && (dev_wave_mt_ >= 0 ? mtb <= dev_wave_mt_ : wave_wins) && !no_small_ && !debug_taps_ && (only < 0 || only == kClsGru);
-    for (int s = 0; wave && s < kStages - 1; ++s)
-        wave = sd_[s + 1].ypad ? sd_[s].head_dim <= 16 : (nby_[s] >= 1 && nby_[s] <= 3 && sd_[s].head_tiles == pi_.npb * nby_[s]);
+    const bool wave = T > 1 && (dev_wave_mt_ >= 0 ? mtb <= dev_wave_mt_ : wave_wins) && !no_small_ && !debug_taps_ && (only < 0 || only == kClsGru) && wave_fits();
     // One-frame bf16 calls whose m-tiles come in whole quads (from 60 m-tiles on): a GRU layer is ONE launch (kns_gruq.hip) -- input
     // GEMM, recurrent GEMM and gates fused over CU quads.  Same arithmetic as the two-kernel form, bit for bit
     // (tests/test_gpu_parity.py::test_alternative_kernels_give_identical_pcm).
@@ -927,47 +980,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     bool head_in_next = false;  // stage s - 1's head has been left to this stage's first layer
     bool head_in_recurrent = false;  // this stage's head was computed by its layer-B recurrent launch
     if (wave) {
-        // m-tiles per workgroup: about two workgroups per CU when the pipeline is full
-        // m-tiles per workgroup (an XCD holds 64 workgroups at a time, a layer has 17 per group; measured best: 1 up to 64 streams,
-        // 3 up to 256, 6 up to 512, 8 beyond -- short groups balance the CUs, long ones pull the weights less often)
-        int mgroup = mtb <= 4 ? 1 : mtb <= 16 ? 3 : mtb <= 32 ? 6 : 8;
-        if (dev_wave_group_ > 0) mgroup = dev_wave_group_;
-        tick(kClsGru);
-        launch_gru_wave_prev(d_hstate_[hs_cur_], d_hprev_, kGruLayers * mtb, prec_, stream_);
-        tock(kClsGru);
-        for (int k = 0; k < T + kWaveItems - 1; ++k) {
-            GruWaveArgs w;
-            w.mgroup = mgroup;
-#ifdef KNS_TIMING
-            w.stamp = k == T / 2 + 5;
-#endif
-            w.layer_wgs = kUnitTiles * ((mtb + mgroup - 1) / mgroup);
-            for (int x = 0; x < 8; ++x) w.layer_item[x] = w.head_item[x] = -1, w.layer_part[x] = 0;
-            int n = 0, layers = 0;
-            const int i0 = k < T ? 0 : k - T + 1;
-            for (int i = i0; i <= k && i < kWaveItems; ++i) layers += i % 3 != 2;
-            // one layer per XCD; four or fewer layers (the pipeline filling or draining) take 2, 4 or 8 XCDs each
-            w.parts = dev_wave_parts_ ? (layers <= 1 ? 8 : layers <= 2 ? 4 : layers <= 4 ? 2 : 1) : 1;
-            w.xcd_wgs = (w.layer_wgs + w.parts - 1) / w.parts;
-            int seen = 0;
-            for (int i = i0; i <= k && i < kWaveItems; ++i) {
-                w.item[n] = wave_item(i, k - i);
-                if (i % 3 == 2) {  // the head of stage s: beside a layer's workgroups, on the XCD(s) of the layer before it in this launch
-                    w.head_item[w.parts == 1 ? 2 * (i / 3) + 1 : (seen ? seen - 1 : 0) * w.parts] = n;
-                } else {
-                    for (int q = 0; q < w.parts; ++q) {
-                        const int x = w.parts == 1 ? 2 * (i / 3) + i % 3 : seen * w.parts + q;  // (all eight in flight: layer l on XCD l)
-                        w.layer_item[x] = n;
-                        w.layer_part[x] = q;
-                    }
-                    ++seen;
-                }
-                ++n;
-            }
-            tick(kClsGru);
-            launch_gru_wave(w, prec_, mtb, stream_);
-            tock(kClsGru);
-        }
+        run_wave(T, mtb);
         if (!mask_in_synthesis)
             gemm(kClsGemmHead, nullptr, 0, d_hseq_b_, nbh_, sd_[kStages - 1].w_head, sd_[kStages - 1].b_head, d_mask_,
                  sd_[kStages - 1].head_tiles, kBins, kOutMask);

@@ -101,6 +101,12 @@ private:
     int16_t *d_in_ = nullptr, *d_out_ = nullptr, *h_in_ = nullptr, *h_out_ = nullptr;
     // host-pointer calls with more than one sub-chunk: copy-in, compute and copy-out run on three streams
     bool process_host_pipelined(int T, const int16_t *pcm, int16_t *out, bool pinned, std::string *err);
+    // calls of several frames as a wavefront over (stage, frame): kns_engine.cpp, run_wave
+    GruSmallArgs small_args(int mtb, const void *a0, int nb0, const void *a1, const void *wih, const float *bih, const void *whh,
+                            const float *bhh, int layer, void *hseq, int t, const StageDev *head) const;
+    GruWaveItem wave_item(int i, int t, int mtb) const;
+    bool wave_fits() const;
+    void run_wave(int T, int mtb);
     hipStream_t copy_in_ = nullptr, copy_out_ = nullptr;
     hipEvent_t ev_in_[2] = {nullptr, nullptr}, ev_done_[2] = {nullptr, nullptr}, ev_out_[2] = {nullptr, nullptr};
     int host_chunk_ = 1;
