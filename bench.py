@@ -317,9 +317,22 @@ def extra_points(args, torch, np, koala_amd, model, kb, x, dx, dy, base, local_r
             'workload': 'BASELINE configs[1]: 256 streams x %d frame(s) per call, fp32 mask net, device-resident' % T1,
             'frames_per_s': round(fps1, 1), 'ms_per_call': round(dt / n * 1e3, 4),
             # the whole mask network against the fp32 matrix peak: the fp32 configuration is the bit-exact correctness path (fp32 =
-            # oracle, value for value), launch-per-frame at this size (profiles/r04_fp32_persist.txt)
+            # oracle, value for value); T = 32 runs as a wavefront over (layer, frame), T = 1 as one launch per layer (DESIGN.md
+            # section 6, profiles/r04_wavefront.txt)
             'roofline': {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': MFMA_PEAK_TFLOPS['fp32'], 'unit': 'TFLOP/s',
                          'frac': round(tflops / MFMA_PEAK_TFLOPS['fp32'], 4), 'flop_per_stream_frame': 2 * (MAC_GEMM_IN + MAC_GRU + MAC_HEAD)}}
+        k1.delete()
+
+    # -- the many-files mode's shape (koala_amd/demo/koala_demo_file.py: a few files x 32 frames per call): 16 streams, both precisions
+    for prec in ('bf16', 'fp32'):
+        k1 = koala_amd.create_batch('bench', 16, 32, prec, model_path=model, device=dev, library_path=args.library)
+        k1.set_stream(torch.cuda.current_stream().cuda_stream)
+        a = torch.from_numpy(np.ascontiguousarray(base[:16, :32 * 256])).cuda()
+        b = torch.empty_like(a)
+        dt = time_steps(lambda: k1.process_device(32, a.data_ptr(), b.data_ptr()), sync, 100, 10)
+        out['files_b16_T32_%s' % prec] = {'workload': '16 streams x 32 frames per call, %s, device-resident (wavefront route)' % prec,
+                                          'frames_per_s': round(16 * 32 * 100 / dt, 1), 'ms_per_call': round(dt / 100 * 1e3, 4),
+                                          'real_time_factor': round(dt / 100 / (16 * 32 * 0.016), 6)}
         k1.delete()
 
     # -- BASELINE configs[4]: one stream, one frame per pv_koala_process call (hipGraph replay, host buffers)
