@@ -322,14 +322,15 @@ __global__ __launch_bounds__(192) void gru_small_kernel(GruSmallArgs g) {
     gru_small_body<P, NB0, kHead, kPad>(g, blockIdx.x, blockIdx.y, hbuf, hspare, ybuf, xch);
 }
 
-// ---- multi-frame calls of few streams: a WAVEFRONT over (layer, frame).  Layer l of frame t needs layer l - 1 of frame t and layer
-// l of frame t - 1, so the items of one anti-diagonal -- one per pipeline stage: the eight GRU layers and the three narrow heads
-// between the stages -- are independent and run side by side in ONE launch (blockIdx.y = item): T + 10 launches per call instead
-// of 8 T, each with enough workgroups for the chip.  A workgroup owns (item, unit tile, group of m-tiles): the three gate waves
-// keep their W_ih and W_hh fragments in registers for the whole group (a CU pulls them once per launch instead of once per m-tile),
-// the m-tile's operands -- x blocks from memory, h_{t-1} converted from its fp32 tiles -- are staged through LDS by the three waves
-// together, and two workgroups per CU cover each other's memory round trips.  The arithmetic is gru_small_body's, operation for
-// operation (same chains, same k order, gi rounded to its storage type, same gate formulas), so the PCM does not depend on the route.
+// ---- calls of several frames as a WAVEFRONT over (layer, frame).  Layer l of frame t needs layer l - 1 of frame t and layer l of
+// frame t - 1, so the items of one anti-diagonal -- one per pipeline stage: the eight GRU layers and the three narrow heads between
+// the stages -- are independent and run side by side in ONE launch: T + 10 launches per call instead of 8 T, each with enough
+// workgroups for the chip.  One layer per XCD (gru_wave_kernel below).  A layer workgroup owns (unit tile, group of m-tiles) and has
+// four waves: three MFMA waves (gates r, z, n) and one that requests operands and does the gate arithmetic (details in the body);
+// the operands of an m-tile -- y, x and h_{t-1}, all in operand form -- go from memory straight into LDS.  The arithmetic is
+// gru_small_body's, operation for operation (same chains, same k order, gi rounded to its storage type, same gate formulas), so
+// the PCM does not depend on the route.  Measured and not adopted: DESIGN.md section 6 (one barrier per m-tile with an LDS flag:
+// races; a five-wave bf16 form: fewer workgroups per CU, slower).
 template <class P, int NB0>
 __device__ __forceinline__ void gru_wave_layer(const GruWaveItem &it, const int u, const int m0, const int m1, const int role, char *obuf,
                                                f32x4 *xch, const bool dbg_stamp) {
