@@ -782,10 +782,11 @@ void Engine::run_wave(int T, int mtb) {
 //   |                               |                                                     | synthesis kernel (not if in == out)  |
 //   | front-end GEMM                | none: folded into the stage-input GEMMs (one-frame  | bf16, T > 1: none either; fp32 and   |
 //   |                               | front-end); five-frame: gemm_front5_t1_kernel       | KNS-v1.1: gemm_wsr / front5 / generic |
-//   | narrow heads 1 / 5 / 40       | inside the next stage's first layer launch          | bf16, T > 1: 1 and 5 inside their    |
+//   | narrow heads 1 / 5 / 40       | inside the next stage's first layer launch          | wavefront: items of their own; bf16  |
+//   |                               |                                                     | chunked: 1 and 5 inside their        |
 //   |                               |                                                     | layer-B recurrent launch; gemm_head  |
 //   | mask head                     | inside the synthesis launch                         | gemm_wsr_kernel                      |
-//   | analysis / synthesis segments | one                                                 | ~4 / ~2 workgroups per CU (>= 4 frames) |
+//   | analysis / synthesis segments | one                                                 | ~4 / ~2 workgroups per CU (>= 1 frame)  |
 //   Host-pointer calls: >= 4 MiB and more than min(16, max_frames / 2) frames -> sub-chunks on three streams; T = 1 -> hipGraph replay.
 enum Route { kRouteChunked = 0, kRouteSmall = 1, kRouteSmallSteps = 2, kRouteQuad1 = 3, kRouteWave = 4 };
 
