@@ -1,4 +1,5 @@
-// kns_gru.hip -- recurrent halves of the GRU layers: streaming, resident (4 and 8 waves), low-latency.
+// kns_gru.hip -- the GRU layers: recurrent halves streaming and resident (8 waves), whole layers of one frame
+// (low-latency kernel) and of several frames as a wavefront over (layer, frame).
 #include "kns_device.hpp"
 
 namespace kns {
