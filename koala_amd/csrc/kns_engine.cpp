@@ -710,8 +710,8 @@ bool Engine::wave_fits() const {  // every head either goes into the features' p
 
 void Engine::run_wave(int T, int mtb) {
     // m-tiles per workgroup (an XCD holds 64 workgroups at a time, a layer has 17 per group; measured best: 1 up to 64 streams,
-    // 3 up to 256, 6 up to 512, 8 beyond -- short groups balance the CUs, long ones pull the weights less often)
-    int mgroup = mtb <= 4 ? 1 : mtb <= 16 ? 3 : mtb <= 32 ? 6 : 8;
+    // 3 up to 256, 6 up to 1 024, 8 beyond -- short groups balance the CUs, long ones pull the weights less often)
+    int mgroup = mtb <= 4 ? 1 : mtb <= 16 ? 3 : mtb <= 64 ? 6 : 8;
     if (dev_wave_group_ > 0) mgroup = dev_wave_group_;
     tick(kClsGru);
     launch_gru_wave_prev(d_hstate_[hs_cur_], d_hprev_, kGruLayers * mtb, prec_, stream_);
