@@ -710,8 +710,9 @@ bool Engine::wave_fits() const {  // every head either goes into the features' p
 
 void Engine::run_wave(int T, int mtb) {
     // m-tiles per workgroup (an XCD holds 64 workgroups at a time, a layer has 17 per group; measured best: 1 up to 64 streams,
-    // 3 up to 256, 6 up to 1 024, 8 beyond -- short groups balance the CUs, long ones pull the weights less often)
-    int mgroup = mtb <= 4 ? 1 : mtb <= 16 ? 3 : mtb <= 64 ? 6 : 8;
+    // 3 up to 256 (fp32: 512), then 6 in bf16, 4 up to 2 048 and 8 beyond in fp32 -- short groups balance the CUs, long ones pull the
+    // weights less often; within ~3 % of the best of {1, 2, 3, 4, 6, 8} at every size swept, profiles/r04_wavefront.txt)
+    int mgroup = mtb <= 4 ? 1 : prec_ == kBf16 ? (mtb <= 16 ? 3 : 6) : (mtb <= 32 ? 3 : mtb <= 128 ? 4 : 8);
     if (dev_wave_group_ > 0) mgroup = dev_wave_group_;
     tick(kClsGru);
     launch_gru_wave_prev(d_hstate_[hs_cur_], d_hprev_, kGruLayers * mtb, prec_, stream_);
