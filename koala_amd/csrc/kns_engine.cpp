@@ -763,7 +763,7 @@ void Engine::run_wave(int T, int mtb) {
 //   | bf16          | 1        | >= 60 and mtb % 4 == 0                | kRouteQuad1: gru_quad1_kernel, one launch per layer; stage    |
 //   |               |          |                                       |   inputs wider than 2 k-blocks: input GEMM + recurrent kernel |
 //   | bf16          | 1        | > 192 and mtb % 4 != 0                | kRouteChunked                                                 |
-//   | bf16          | > 1      | <= 32 (<= 64 up to T = 4)             | kRouteWave: gru_wave_kernel, T + 10 launches: the (stage,     |
+//   | bf16          | > 1      | <= 48 (<= 64 up to T = 4)             | kRouteWave: gru_wave_kernel, T + 10 launches: the (stage,     |
 //   |               |          |                                       |   frame) items of one anti-diagonal side by side, one layer   |
 //   |               |          |                                       |   per XCD, narrow heads as items of their own                 |
 //   | bf16          | > 1      | otherwise                             | kRouteChunked: gemm_ws2 (m-tiles in multiples of 256 x stage; |
@@ -927,10 +927,10 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         tock(kClsGru);
     };
     // Where it wins (measured against the other routes, tools/wave_check.py, profiles/r04_wavefront.txt): fp32 at every size measured
-    // (2 frames x 256 streams: 0.19 against 0.23 ms; 32 x 256: 1.13 against 2.52; 32 x 4 096: 11.4 against 13.5); bf16 up to 512 streams
-    // (32 frames: 0.49 against 0.68 ms; 768 streams: equal; beyond, the chunked kernels' resident weights win -- 1 024 x 32: 0.81
-    // against 0.76 ms -- except in calls of 2-4 frames)
-    const bool wave_wins = prec_ == kBf16 ? (mtb <= 32 || (mtb <= 64 && T <= 4)) : mtb <= 256;
+    // (2 frames x 256 streams: 0.19 against 0.23 ms; 32 x 256: 1.13 against 2.52; 32 x 4 096: 11.4 against 13.5); bf16 up to 768 streams
+    // (32 frames x 512 streams: 0.49 against 0.68 ms; 768: 0.66 against 0.73; 1 024: equal at best -- beyond, the chunked kernels'
+    // resident weights win -- except in calls of 2-4 frames)
+    const bool wave_wins = prec_ == kBf16 ? (mtb <= 48 || (mtb <= 64 && T <= 4)) : mtb <= 256;
     const bool wave = T > 1 && (dev_wave_mt_ >= 0 ? mtb <= dev_wave_mt_ : wave_wins) && !no_small_ && !debug_taps_ && (only < 0 || only == kClsGru) && wave_fits();
     // One-frame bf16 calls whose m-tiles come in whole quads (from 60 m-tiles on): a GRU layer is ONE launch (kns_gruq.hip) -- input
     // GEMM, recurrent GEMM and gates fused over CU quads.  Same arithmetic as the two-kernel form, bit for bit

@@ -601,12 +601,12 @@ def test_baseline_config1_b256_fp32_at_its_stated_size(random_model, T, calls):
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
 @pytest.mark.parametrize('B,T', [(256, 1), (272, 1), (944, 1), (960, 1), (976, 1), (1792, 1), (3072, 1), (3088, 1), (4090, 1), (4096, 1), (4112, 1), (8192, 1), (3072, 2),
-                                 (3088, 2), (512, 5), (528, 5), (1024, 3), (1040, 3), (4112, 2)])
+                                 (3088, 2), (768, 5), (784, 5), (1024, 3), (1040, 3), (4112, 2)])
 def test_dispatch_boundaries(random_model, precision, B, T):
     """The engine switches kernel families between one-frame calls below and above 192 m-tiles (bf16) / 256 m-tiles (fp32)
     (low-latency layer kernel vs input GEMM + recurrent kernel; 16 m-tiles was the edge in round 1), in bf16 already at
     59 -> 60 m-tiles when the m-tiles make whole quads (one-step fused quad kernel; 61 m-tiles do not); calls of several frames
-    change between the wavefront route and the chunked kernels at 32 / 64 m-tiles (bf16) and 256 (fp32), kns_engine.cpp
+    change between the wavefront route and the chunked kernels at 48 / 64 m-tiles (bf16) and 256 (fp32), kns_engine.cpp
     run_device().  Both sides of every edge, two calls each, every stream against the oracle."""
     base = synth_streams(128, 2 * T, seed=B)
     x = np.tile(base, ((B + 127) // 128, 1))[:B]
@@ -624,7 +624,7 @@ def test_dispatch_boundaries(random_model, precision, B, T):
 
 @pytest.mark.parametrize('precision,B,T,route', [('bf16', 16, 1, 1), ('bf16', 944, 1, 1), ('bf16', 960, 1, 3), ('bf16', 976, 1, 1),
                                                  ('bf16', 3072, 1, 3), ('bf16', 3088, 1, 0), ('bf16', 4096, 1, 3), ('bf16', 64, 4, 4),
-                                                 ('bf16', 512, 8, 4), ('bf16', 528, 8, 0), ('bf16', 1024, 4, 4), ('bf16', 1024, 5, 0), ('bf16', 1040, 2, 0),
+                                                 ('bf16', 768, 8, 4), ('bf16', 784, 8, 0), ('bf16', 1024, 4, 4), ('bf16', 1024, 5, 0), ('bf16', 1040, 2, 0),
                                                  ('bf16', 4096, 4, 0), ('fp32', 256, 1, 1), ('fp32', 4096, 1, 1), ('fp32', 4112, 1, 0),
                                                  ('fp32', 64, 2, 4), ('fp32', 256, 32, 4), ('fp32', 4096, 2, 4), ('fp32', 4112, 2, 0)])
 def test_dispatch_routes(random_model, precision, B, T, route):

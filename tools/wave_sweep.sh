@@ -8,7 +8,7 @@ echo "# layer-by-layer routes (fp32: gru_small_kernel frame by frame / chunked k
 echo "# tools/wave_check.py, one MI355X box, device-resident PCM, 50 calls timed after 5; 'max |diff|' = the two routes' PCM over"
 echo "# three consecutive calls (state carried).  Commit $(git rev-parse --short HEAD 2>/dev/null || echo '?')."
 echo
-echo "## 32 frames per call, wavefront forced at every size (the engine takes it in fp32 at every size up to 4 096 streams, in bf16 up to 512)"
+echo "## 32 frames per call, wavefront forced at every size (the engine takes it in fp32 at every size up to 4 096 streams, in bf16 up to 768)"
 WAVE_T=32 run 16 64 128 256 512 1024 2048 4096
 echo
 echo "## 256 and 512 streams, frames per call swept"
