@@ -14,7 +14,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <memory>
 #include <mutex>
+#include <new>
 #include <thread>
 
 namespace kns {
@@ -161,6 +163,53 @@ std::vector<uint8_t> pack_b(const float *W, int ldw, const std::vector<Seg> &seg
     return out;
 }
 
+// row[n] = fma(a[j], W[j][n], row[n]), j ascending: one row of the front-end fold (4 x 257 x 271 x 813 fused multiply-adds per handle).
+// Two bodies of the same IEEE operations: the x86-64-v3 one (vfmadd, ~0.1 s per handle) is entered only on a CPU that reports
+// FMA and AVX2; the portable one calls fmaf (correct on any host, seconds per handle).  Nothing else in this file is compiled
+// with wider ISA flags, and -ffp-contract=off keeps every other a * b + c of the packing code two roundings.
+#if defined(__x86_64__)
+__attribute__((target("fma,avx2"))) void fold_row_v3(float *row, const float *a, const float *W, int J, int N) {
+    for (int j = 0; j < J; ++j) {
+        const float aj = a[j];
+        const float *wr = W + (size_t) j * N;
+        for (int n = 0; n < N; ++n) row[n] = __builtin_fmaf(aj, wr[n], row[n]);
+    }
+}
+#endif
+void fold_row_portable(float *row, const float *a, const float *W, int J, int N) {
+    for (int j = 0; j < J; ++j) {
+        const float aj = a[j];
+        const float *wr = W + (size_t) j * N;
+        for (int n = 0; n < N; ++n) row[n] = fmaf(aj, wr[n], row[n]);
+    }
+}
+void fold_row(float *row, const float *a, const float *W, int J, int N) {
+#if defined(__x86_64__)
+    static const bool v3 = __builtin_cpu_supports("fma") && __builtin_cpu_supports("avx2");
+    if (v3) return fold_row_v3(row, a, W, J, N);
+#endif
+    fold_row_portable(row, a, W, J, N);
+}
+
+// true if rows k >= k_from of a B-packed image with nb k-blocks per n-tile are all zero.  The bf16 recurrent kernels publish hidden
+// sequences whose k = 271, 272 hold the constant 1 (the bias rows' operand, kBiasK0), and the narrow heads write their few values
+// into the features' padding columns: every OTHER consumer of those operands relies on its packed weights being zero there.
+bool rows_zero_from(const std::vector<uint8_t> &img, int nb, int k_from, int precision) {
+    const PrecInfo pi = prec_info(precision);
+    const size_t ntiles = img.size() / ((size_t) nb * 1024);
+    for (size_t nt = 0; nt < ntiles; ++nt)
+        for (int blk = k_from / pi.kb; blk < nb; ++blk)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < pi.epl; ++e) {
+                    const int kk = precision == kBf16 ? (lane >> 4) * 8 + e : e * 4 + (lane >> 4);
+                    if (blk * pi.kb + kk < k_from) continue;
+                    const uint8_t *v = img.data() + (nt * nb + blk) * 1024 + (size_t) (lane * pi.epl + e) * pi.esz;
+                    for (int q = 0; q < pi.esz; ++q)
+                        if (v[q]) return false;
+                }
+    return true;
+}
+
 std::vector<float> pack_bias(const float *b, const std::vector<Tile> &tiles) {
     std::vector<float> out(tiles.size() * 16, 0.0f);
     for (size_t nt = 0; nt < tiles.size(); ++nt)
@@ -215,13 +264,18 @@ void *Engine::upload(const void *src, size_t bytes) {
 
 Engine *Engine::create(const Params &p, int device, int num_streams, int max_frames, int precision, std::string *err,
                        bool *oom) {
-    Engine *e = new Engine();
+    // (the handle is owned from its first byte: an exception out of init() -- std::bad_alloc from the packing vectors -- destroys the
+    // stream, events and device allocations made so far and reaches the ABI as "out of memory", not as a leak)
+    std::unique_ptr<Engine> e(new Engine());
     *oom = false;
-    if (!e->init(p, device, num_streams, max_frames, precision, err, oom)) {
-        delete e;
+    try {
+        if (!e->init(p, device, num_streams, max_frames, precision, err, oom)) return nullptr;
+    } catch (const std::bad_alloc &) {
+        *oom = true;
+        *err = "Failed to allocate host memory.";
         return nullptr;
     }
-    return e;
+    return e.release();
 }
 
 bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, std::string *err, bool *oom) {
@@ -330,6 +384,7 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
         b_in_ = (float *) upload(b.data(), b.size() * 4);
     }
     const auto gt = gru_tiles();
+    bool pad_rows_ok = true;  // see rows_zero_from
     for (int s = 0; s < kStages; ++s) {
         const Params::Stage &st = p.st[s];
         StageDev &d = sd_[s];
@@ -349,6 +404,10 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
         };
         auto pk = [&](const std::vector<float> &w, const std::vector<Seg> &segs) {
             auto img = pack_b(gate_scaled(w, w.size() / G3).data(), G3, segs, gt, precision);
+            // (the last segment is the hidden-sized one: its padding rows face the constant 1 of a published hidden sequence)
+            int nb = 0;
+            for (const Seg &sg : segs) nb += ceil_div(sg.klen, pi_.kb);
+            pad_rows_ok = pad_rows_ok && rows_zero_from(img, nb, (nb - nbh_) * pi_.kb + kHidden, precision);
             return upload(img.data(), img.size());
         };
         auto pb = [&](const std::vector<float> &b) {
@@ -386,14 +445,7 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
             std::vector<float> wf((size_t) (st.d_in + kBins) * G3, 0.0f), bf(G3, 0.0f);
             memcpy(wf.data() + (size_t) y0 * G3, ws.data(), sizeof(float) * (size_t) st.d_in * G3);
             const float *we = ws.data() + (size_t) st.d_in * G3;
-            for (int k = 0; k < kBins; ++k) {
-                float *row = wf.data() + (size_t) (f0 + k) * G3;
-                for (int j = 0; j < kHidden; ++j) {
-                    const float a = p.w_in[(size_t) k * kHidden + j];
-                    const float *wr = we + (size_t) j * G3;
-                    for (int n = 0; n < G3; ++n) row[n] = __builtin_fmaf(a, wr[n], row[n]);
-                }
-            }
+            for (int k = 0; k < kBins; ++k) fold_row(wf.data() + (size_t) (f0 + k) * G3, p.w_in.data() + (size_t) k * kHidden, we, kHidden, G3);
             for (int j = 0; j < kHidden; ++j)
                 for (int n = 0; n < G3; ++n) bf[n] = __builtin_fmaf(p.b_in[j], we[(size_t) j * G3 + n], bf[n]);
             for (int n = 0; n < G3; ++n) bf[n] = bs[n] + bf[n];
@@ -405,6 +457,11 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
                 segs_f.push_back({st.d_in, kBins});
             }
             auto img = pack_b(wf.data(), G3, segs_f, gt, precision);
+            {   // columns past [y ; features ; y behind] of the feature operand may hold other stages' head values
+                int nb = 0;
+                for (const Seg &sg : segs_f) nb += ceil_div(sg.klen, pi_.kb);
+                pad_rows_ok = pad_rows_ok && rows_zero_from(img, nb, (nb - nbf_) * pi_.kb + kBins + (d.ypad ? st.d_in : 0), precision);
+            }
             d.w_ih_a = upload(img.data(), img.size());
             auto bimg = pack_bias(bf.data(), gt);
             d.b_ih_a = (float *) upload(bimg.data(), bimg.size() * 4);
@@ -420,12 +477,18 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
         d.b_hh_b = pb(st.b_hh_b);
         auto ht = dense_tiles(st.d_out, s < kStages - 1 ? pi_.npb : 1);
         auto hw = pack_b(st.w_head.data(), st.d_out, {{0, kHidden}}, ht, precision);
+        pad_rows_ok = pad_rows_ok && rows_zero_from(hw, nbh_, kHidden, precision);
         auto hb = pack_bias(st.b_head.data(), ht);
         d.w_head = upload(hw.data(), hw.size());
         d.b_head = (float *) upload(hb.data(), hb.size() * 4);
         d.head_tiles = (int) ht.size();
         d.head_dim = st.d_out;
         nby_[s] = ceil_div(st.d_out, pi_.kb);
+    }
+
+    if (!pad_rows_ok) {
+        *err = "Internal error: a packed weight image has non-zero padding rows.";
+        return false;
     }
 
     // ---- per-stream state

@@ -235,7 +235,7 @@ def make_adaptive_gate(mu: float = -9.0, sigma: float = 0.125, a: float = 0.5, c
                        spread: float = 0.416, thr_lf: float = 0.405, lf_bands: float = 1.6, zb_rel: float = 3.6,
                        ctx: float = 0.0, ctx_width: int = 8, hang: float = 0.3, hang_lo: int = 8, hang_hi: int = 100,
                        hang_gain: float = 4.374, hang_ref: float = 0.81, hang_z0: float = 6.8, hang_z1: float = 9.0,
-                       hang_bands: int = 4) -> Dict[str, np.ndarray]:
+                       hang_bands: int = 4, mask_spread: int = 0) -> Dict[str, np.ndarray]:
     """
     Hand-built spectral gate with an ADAPTIVE noise floor carried in GRU state -- nothing in it is derived from any audio
     file.  (`make_gate` takes its threshold from the mean spectrum of the reference's noise fixture; this one replaces that
@@ -328,9 +328,16 @@ def make_adaptive_gate(mu: float = -9.0, sigma: float = 0.125, a: float = 0.5, c
     bi[0:HIDDEN] = 8.0
     bi[HIDDEN:2 * HIDDEN] = 8.0
     for k in range(BINS):
-        w[nb + band[k], 2 * HIDDEN + k] = g2
+        # (mask_spread > 0: a bin listens to the detectors of its band and `mask_spread` bands either side, triangular weights --
+        # one detector's decision then moves a bin's mask by a fraction of its range, which is what keeps the model's output
+        # insensitive to a single flipped rounding of the bf16 configuration, tools/model_sensitivity.py)
+        qs = [q for q in range(band[k] - mask_spread, band[k] + mask_spread + 1) if 0 <= q < nb]
+        wt = np.array([mask_spread + 1 - abs(q - band[k]) for q in qs], np.float64)
+        wt /= wt.sum()
+        for q, v in zip(qs, wt):
+            w[nb + q, 2 * HIDDEN + k] = g2 * v
+            w[nb + q, HIDDEN + k] = -zb_rel * v  # update gate: fast attack (detector high), slow release (detector low)
         bi[HIDDEN + k] = logit(z_b)
-        w[nb + band[k], HIDDEN + k] = -zb_rel  # update gate: fast attack (detector high), slow release (detector low)
     t["s3.w_ih_b"][:] = w
     t["s3.b_ih_b"][:] = bi
     head = np.zeros((HIDDEN, BINS), np.float64)

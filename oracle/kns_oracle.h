@@ -77,6 +77,12 @@ int kns_oracle_process_mask(kns_oracle_t *o, int num_frames, const int16_t *pcm,
 /* streams per block used by the last kns_oracle_process call (reporting only) */
 int kns_oracle_last_block(void);
 
+/* Sensitivity probe (bf16 mode only; 0 = off, also settable as KNS_ORACLE_JITTER in the environment): the oracle plays a SECOND
+ * valid implementation of the tolerance-specified bf16 configuration -- the last bit of every transcendental result and of some
+ * GEMM outputs moves by one ulp, seeded by (seed, stream, frame).  The PCM distance between a plain and a jittered run of one model
+ * predicts that model's GPU-vs-oracle distance (tools/model_sensitivity.py, tests/test_holdout.py).  Never set in a parity test. */
+void kns_oracle_set_jitter(int seed);
+
 /* single stream (index s), one frame, with taps */
 int kns_oracle_process_tap(kns_oracle_t *o, int s, const int16_t *pcm, int16_t *enhanced, kns_taps_t *taps);
 

@@ -65,12 +65,18 @@ def _bind(l):
     l.kns_oracle_process.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     l.kns_oracle_process_mask.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     l.kns_oracle_process_tap.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(_Taps)]
+    l.kns_oracle_set_jitter.argtypes = [C.c_int]
     l.kns_oracle_analysis.argtypes = [C.c_void_p] * 5
     l.kns_oracle_synthesis.argtypes = [C.c_void_p] * 4
     for n in ("kns_exp", "kns_log", "kns_sigmoid", "kns_tanh", "kns_round_bf16", "kns_round_fp16"):
         getattr(l, n).argtypes = [C.c_float]
         getattr(l, n).restype = C.c_float
     return l
+
+
+def set_jitter(seed: int) -> None:
+    """Sensitivity probe (kns_oracle.h): bf16 oracles of this process play a second valid implementation; 0 = off."""
+    lib().kns_oracle_set_jitter(int(seed))
 
 
 def block_size() -> int:
