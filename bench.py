@@ -70,6 +70,7 @@ def parse_args():
     ap.add_argument('--frames', type=int, default=64, help='frames per stream per call (64 = 1.02 s of audio)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-leg-child', action='store_true', help='internal: the cpu_baseline leg in its own (core-bound) process')
     ap.add_argument('--no-extra', action='store_true', help='skip the other operating points (profiling runs)')
     ap.add_argument('--no-live-traffic', action='store_true', help='do not run the two rocprofv3 --pmc passes that measure HBM bytes '
                     'per launch (then the last committed profiles/*_pmc.json is quoted, marked as not measured in this run)')
@@ -232,6 +233,53 @@ def time_steps(fn, sync, steps, warmup):
         fn()
     sync()
     return time.perf_counter() - t0
+
+
+def physical_cores():
+    """distinct (package, core) pairs of the CPUs this process may run on; falls back to the logical count"""
+    try:
+        seen = set()
+        for c in os.sched_getaffinity(0):
+            base = '/sys/devices/system/cpu/cpu%d/topology/' % c
+            seen.add((open(base + 'physical_package_id').read().strip(), open(base + 'core_id').read().strip()))
+        return max(1, len(seen))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def cpu_leg_child(T, distinct):
+    """The cpu_baseline leg proper, in its own process (started by main() with the OpenMP binding in its environment): the oracle
+    ("port") on a bounded sample of the bench workload -- calibrated for ~15 s -- plus one thread for scale.  Prints one JSON line."""
+    import numpy as np
+    from koala_amd import params
+    from koala_amd.workload import synth_streams
+    from oracle import oracle
+    model = params.ensure_params(os.path.join(ROOT, 'build', 'random_1234.kns'), 'random', 1234)
+    native = oracle.build_native()
+    threads = int(os.environ.get('OMP_NUM_THREADS', '0')) or (os.cpu_count() or 1)
+    base = synth_streams(distinct, T, seed=1234)
+    xs = np.ascontiguousarray(np.tile(base, ((1024 + distinct - 1) // distinct, 1))[:1024, :8 * 256])
+    o = oracle.Oracle(model, 1024, oracle.PREC_FP32, library=native)
+    o.process(xs, threads)  # (first touch, thread start-up)
+    c0 = time.perf_counter()
+    o.process(xs, threads)
+    rate = 1024 * 8 / (time.perf_counter() - c0)
+    ns = int(min(32768, max(64, (rate * 15) // (T * 64) * 64)))
+    o = oracle.Oracle(model, ns, oracle.PREC_FP32, library=native)
+    xs = np.ascontiguousarray(np.tile(base, ((ns + distinct - 1) // distinct, 1))[:ns])
+    c0 = time.perf_counter()
+    o.process(xs, threads)
+    dt = time.perf_counter() - c0
+    block = oracle.block_size()
+    n1 = 64  # one thread, for scale: the multi-thread figure is a weak baseline (shared weights, 64-stream blocks per thread)
+    o1 = oracle.Oracle(model, n1, oracle.PREC_FP32, library=native)
+    x1 = np.ascontiguousarray(np.tile(base, ((n1 + distinct - 1) // distinct, 1))[:n1, :16 * 256])
+    c1 = time.perf_counter()
+    o1.process(x1, 1)
+    rate1 = n1 * 16 / (time.perf_counter() - c1)
+    print(json.dumps({'frames_per_s': round(ns * T / dt, 1), 'threads': threads, 'streams': ns, 'seconds': round(dt, 1), 'block': block,
+                      'one_thread_frames_per_s': round(rate1, 1),
+                      'build': '-O3 -march=native (this host)' if native.endswith('_native.so') else '-O3 -march=x86-64-v3'}))
 
 
 def machine_state():
@@ -573,38 +621,33 @@ def main():
         # checks below use the portable build that travels with the repository: same source, same results bit for bit) and
         # starts once the box is quiet -- the 1-minute load average below 4, waited for at most 45 s (it decays with a 60 s time
         # constant: after the GPU legs' host threads it starts around 15-30)
-        native = oracle.build_native()
+        # The timed leg runs in a CHILD process (cpu_leg_child below): its OpenMP runtime starts from a clean environment -- one thread
+        # per physical core, bound (OMP_PLACES=cores, OMP_PROC_BIND=close: a block's scratch is first touched, hence allocated, on the
+        # NUMA node of the core that works on it), no torch thread pools beside it -- on the oracle compiled for THIS host's instruction
+        # set (-march=native, built here and now; the parity checks below use the portable build that travels with the repository:
+        # same source, same results bit for bit).  It starts once the box is quiet -- the 1-minute load average below 4, waited for at
+        # most 45 s (it decays with a 60 s time constant: after the GPU legs' host threads it starts around 15-30); a leg that had
+        # to start on a busy box says so: "noisy": true.
         t_wait = time.perf_counter()
         while machine_state().get('loadavg_1m', 0.0) >= 4.0 and time.perf_counter() - t_wait < 45.0:
             time.sleep(1.0)
         waited = time.perf_counter() - t_wait
         before = machine_state()
         before['waited_for_quiet_s'] = round(waited, 1)
-        # calibrate, then size the sample for ~10-20 s of CPU work
-        o = oracle.Oracle(model, 1024, oracle.PREC_FP32, library=native)
-        xs = np.ascontiguousarray(x[:1024, :8 * 256]) if B >= 1024 else np.ascontiguousarray(np.tile(base, (16, 1))[:1024, :8 * 256])
-        c0 = time.perf_counter()
-        o.process(xs)
-        rate = 1024 * 8 / (time.perf_counter() - c0)
-        ns = int(min(16384, max(64, (rate * 15) // (T * 64) * 64)))
-        o = oracle.Oracle(model, ns, oracle.PREC_FP32, library=native)
-        xs = np.ascontiguousarray(np.tile(base, ((ns + distinct - 1) // distinct, 1))[:ns])
-        c0 = time.perf_counter()
-        o.process(xs)
-        dt = time.perf_counter() - c0
-        # one thread, for scale: the multi-thread figure is a weak baseline (shared weights, 64-stream blocks per thread)
-        n1 = 64
-        o1 = oracle.Oracle(model, n1, oracle.PREC_FP32, library=native)
-        x1 = np.ascontiguousarray(np.tile(base, ((n1 + distinct - 1) // distinct, 1))[:n1, :16 * 256])
-        c1 = time.perf_counter()
-        o1.process(x1, 1)
-        rate1 = n1 * 16 / (time.perf_counter() - c1)
-        cpu = {'value': round(ns * T / dt, 1), 'unit': 'frames/s', 'cores': ncores, 'kind': 'port',
-               'one_thread_frames_per_s': round(rate1, 1), 'scaling_vs_1_thread': round(ns * T / dt / rate1, 1),
-               'build': '-O3 -march=native (this host)' if native.endswith('_native.so') else '-O3 -march=x86-64-v3',
+        phys = physical_cores()
+        env = dict(os.environ, OMP_PLACES='cores', OMP_PROC_BIND='close', OMP_NUM_THREADS=str(phys), OMP_DYNAMIC='false')
+        env.pop('KNS_ORACLE_JITTER', None)
+        child = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-leg-child', '--frames', str(T), '--streams', str(distinct)],
+                               env=env, stdout=subprocess.PIPE, timeout=600)
+        leg = json.loads(child.stdout.decode().strip().splitlines()[-1])
+        cpu = {'value': leg['frames_per_s'], 'unit': 'frames/s', 'cores': leg['threads'], 'kind': 'port',
+               'host_logical_cpus': ncores, 'binding': 'OMP_PLACES=cores OMP_PROC_BIND=close, one thread per physical core, own process',
+               'noisy': bool(before.get('loadavg_1m', 0.0) >= 4.0),
+               'one_thread_frames_per_s': leg['one_thread_frames_per_s'], 'scaling_vs_1_thread': round(leg['frames_per_s'] / leg['one_thread_frames_per_s'], 1),
+               'build': leg['build'],
                'sample': '%d streams x %d frames of the same synthetic workload, oracle/kns_oracle.c fp32 (register-blocked '
                          'k-ascending fmaf GEMMs, OpenMP over stream blocks of %d), %.1f s'
-                         % (ns, T, oracle.block_size(), dt),
+                         % (leg['streams'], T, leg['block'], leg['seconds']),
                'machine_state_before': before, 'machine_state_after': machine_state()}
         # parity of the timed engine's first call against the oracle run with the same rounding points, over every
         # distinct stream of the batch
@@ -748,4 +791,8 @@ def main():
 
 
 if __name__ == '__main__':
+    if '--cpu-leg-child' in sys.argv:  # (before anything touches torch or the GPU)
+        a = parse_args()
+        cpu_leg_child(a.frames, a.streams)
+        sys.exit(0)
     main()

@@ -66,7 +66,7 @@ def sensitivity(model, x):
         y = oracle.Oracle(model, x.shape[0], oracle.PREC_BF16).process(x, 1)
         d = np.abs(y.astype(np.int64) - ref.astype(np.int64))
         worst = max(worst, int(d.max()))
-        big += int((d > 3).sum())
+        big += int((d > 2).sum())
     oracle.set_jitter(0)
     return worst, big
 
@@ -78,7 +78,7 @@ def evaluate(kw):
     if not _ctx:
         _ctx['t'] = load_wav('test.wav')
         _ctx['z'] = load_wav('noise.wav')
-        x = synth_streams(48, 100, seed=5000)
+        x = synth_streams(192, 100, seed=5000)
         n = 100 * 256
         t, z = _ctx['t'], _ctx['z']
         for i, w in enumerate((t, z, (t.astype(int) + z).astype(np.int16))):
@@ -105,7 +105,7 @@ def cost(res):
     c = max(0.0, res['env'] - 0.0185) * 4000.0  # the envelope is the hard constraint
     if 'sens' not in res:
         return c + 1000.0
-    c += res['sens'] + 0.002 * res['big']
+    c += res['sens'] + 0.01 * res['big']
     h = res.get('hold')
     if h:
         c += 10 * max(0.0, 16.0 - h['steady_db']) + 10 * max(0.0, 9.0 - h['first_frames_db']) + 200 * max(0.0, 0.87 - h['speech_ratio'])

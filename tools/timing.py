@@ -3,16 +3,17 @@ import ctypes as C, os, subprocess, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-lib = os.path.join(ROOT, 'build', 'libpv_koala_timing.so')
+lib = os.path.join(ROOT, 'build', 'libpv_koala_timing%s.so' % os.environ.get('TIMING_TAG', ''))
 os.makedirs(os.path.dirname(lib), exist_ok=True)
 src = [os.path.join(ROOT, 'koala_amd', 'csrc', f) for f in ('kns_stft.hip', 'kns_gemm.hip', 'kns_gru.hip', 'kns_gruq.hip', 'kns_engine.cpp', 'pv_api.cpp')]
-subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
-                       '-ffp-contract=off', '-Xarch_host', '-mfma', '-Xarch_host', '-mavx2', '-DKNS_TIMING', '-x', 'hip'] + src + ['-shared', '-o', lib])
+if not (os.environ.get('TIMING_NOBUILD') and os.path.exists(lib)):
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden',
+                       '-ffp-contract=off', '-DKNS_TIMING'] + os.environ.get('TIMING_FLAGS', '').split() + ['-x', 'hip'] + src + ['-shared', '-o', lib])
 import koala_amd
 from koala_amd import params
 from koala_amd.workload import synth_streams
 model = params.ensure_params(os.path.join(ROOT, 'build', 'random_1234.kns'), 'random', 1234)
-B, T = 4096, 32
+B, T = 4096, int(os.environ.get('TIMING_T', 32))
 x = torch.from_numpy(np.tile(synth_streams(64, T, 1), (B // 64, 1))).cuda()
 y = torch.empty_like(x)
 kb = koala_amd.create_batch('k', B, T, 'bf16', model_path=model, library_path=lib)
