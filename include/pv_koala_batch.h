@@ -45,6 +45,16 @@ PV_API pv_status_t pv_koala_batch_process(pv_koala_batch_t *object, const int16_
 PV_API pv_status_t pv_koala_batch_process_chunk(pv_koala_batch_t *object, int32_t num_frames, const int16_t *pcm,
                                                 int16_t *enhanced);
 
+/* The same for a throughput-oriented host caller (a many-files batch job that double-buffers its I/O): `pcm` and `enhanced` must be
+ * PAGE-LOCKED host memory (pv_koala_batch_host_alloc, hipHostMalloc, hipHostRegister; anything else is refused with
+ * PV_STATUS_RUNTIME_ERROR, nothing processed).  The call enqueues its copy-in, kernels and copy-out and RETURNS; up to two such calls are
+ * in flight per handle (a third first waits for the oldest), so one call's copies run under its neighbours' kernels -- a synchronous
+ * call cannot hide its first copy-in and last copy-out.  Calls complete in order; `enhanced` of a call is valid, and `pcm` may be
+ * reused, once pv_koala_batch_synchronize() has returned or two further asynchronous calls have been accepted.  Every other entry
+ * point of the handle first waits for the calls in flight.  `enhanced` may equal `pcm`. */
+PV_API pv_status_t pv_koala_batch_process_chunk_async(pv_koala_batch_t *object, int32_t num_frames, const int16_t *pcm,
+                                                      int16_t *enhanced);
+
 /* Resets the streams whose byte in `stream_mask[num_streams]` (host memory) is non-zero; NULL resets all. */
 PV_API pv_status_t pv_koala_batch_reset(pv_koala_batch_t *object, const uint8_t *stream_mask);
 
@@ -60,7 +70,7 @@ PV_API void pv_koala_batch_host_free(void *memory);
 
 /* Run on a caller-provided HIP stream (a hipStream_t passed as void*; NULL = the handle's own stream). */
 PV_API pv_status_t pv_koala_batch_set_stream(pv_koala_batch_t *object, void *hip_stream);
-/* Blocks until everything enqueued by this handle has finished. */
+/* Blocks until everything enqueued by this handle -- device-pointer calls, asynchronous host calls -- has finished. */
 PV_API pv_status_t pv_koala_batch_synchronize(pv_koala_batch_t *object);
 
 /* Per-kernel timing with HIP events recorded on the handle's stream (bench.py's roofline leg).

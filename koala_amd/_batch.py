@@ -32,7 +32,8 @@ class KoalaBatch(object):
         self._lib = lib
         lib.pv_koala_batch_init.argtypes = [c_char_p, c_char_p, c_char_p, c_int32, c_int32, c_int32, POINTER(c_void_p)]
         lib.pv_koala_batch_init.restype = PicovoiceStatuses
-        for name, args in (('process_chunk', [c_void_p, c_int32, c_void_p, c_void_p]), ('reset', [c_void_p, c_void_p]),
+        for name, args in (('process_chunk', [c_void_p, c_int32, c_void_p, c_void_p]), ('process_chunk_async', [c_void_p, c_int32, c_void_p, c_void_p]),
+                           ('reset', [c_void_p, c_void_p]),
                            ('set_stream', [c_void_p, c_void_p]), ('synchronize', [c_void_p]),
                            ('profile_enable', [c_void_p, c_int32]),
                            ('profile_read', [c_void_p, POINTER(c_double), POINTER(c_int64)]),
@@ -98,6 +99,18 @@ class KoalaBatch(object):
                     "expected C-contiguous int16 arrays of shape [%d, T*%d]" % (self.num_streams, self.frame_length))
         self._check(self._lib.pv_koala_batch_process_chunk(self._handle, pcm.shape[1] // self.frame_length,
                                                            pcm.ctypes.data, enhanced.ctypes.data), 'Processing failed')
+
+    def process_async(self, pcm: np.ndarray, enhanced: np.ndarray) -> None:
+        """`process_into()` without the wait, for page-locked arrays (`alloc_host()`): the call is enqueued and returns; up to two are
+        in flight, so a caller that alternates between two buffer pairs keeps the link and the GPU busy at once.  `enhanced` is valid
+        after `synchronize()` (or once two further asynchronous calls have been accepted)."""
+        for a in (pcm, enhanced):
+            if (not isinstance(a, np.ndarray) or a.dtype != np.int16 or not a.flags['C_CONTIGUOUS'] or a.ndim != 2 or
+                    a.shape[0] != self.num_streams or a.shape[1] % self.frame_length or a.shape != pcm.shape):
+                raise KoalaInvalidArgumentError(
+                    "expected C-contiguous int16 arrays of shape [%d, T*%d]" % (self.num_streams, self.frame_length))
+        self._check(self._lib.pv_koala_batch_process_chunk_async(self._handle, pcm.shape[1] // self.frame_length,
+                                                                 pcm.ctypes.data, enhanced.ctypes.data), 'Processing failed')
 
     def process_device(self, num_frames: int, pcm_ptr: int, enhanced_ptr: int) -> None:
         """Device pointers (e.g. torch_tensor.data_ptr()) of int16 [num_streams, num_frames*256]; asynchronous."""

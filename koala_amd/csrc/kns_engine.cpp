@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -538,6 +539,14 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
         *err = "Failed to allocate pinned host memory.";
         return false;
     }
+    d_frame_count_ = (unsigned *) dalloc(64, true);
+    if (hipHostMalloc((void **) &h_frame_word_, 64, hipHostMallocDefault) != hipSuccess) {
+        (void) hipGetLastError();
+        h_frame_word_ = nullptr;  // (no completion word: one-frame replays wait in hipStreamSynchronize)
+    } else {
+        *h_frame_word_ = 0;
+    }
+    spin_wait_ = dev_env("KOALA_AMD_NO_SPIN_WAIT") == nullptr;
     if (taps_ > 1) {  // the front-end context of a fresh stream is silence, not zeros
         AnalysisArgs an;
         an.pcm = d_in_;  // zeros (at least one frame of B_ >= 1 streams; rows past the last stream re-read the last one)
@@ -572,6 +581,7 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
 
 Engine::~Engine() {
     if (own_stream_) (void) hipStreamSynchronize(own_stream_);
+    if (copy_out_) (void) hipStreamSynchronize(copy_out_);  // (asynchronous host calls still writing into the caller's buffers)
     for (Span &s : spans_) {
         (void) hipEventDestroy(s.a);
         (void) hipEventDestroy(s.b);
@@ -580,9 +590,13 @@ Engine::~Engine() {
     for (hipGraphExec_t ge : frame_graph_)
         if (ge) (void) hipGraphExecDestroy(ge);
     for (void *p : allocs_) (void) hipFree(p);
+    if (h_frame_word_) (void) hipHostFree(h_frame_word_);
     if (h_in_) (void) hipHostFree(h_in_);
     if (h_out_) (void) hipHostFree(h_out_);
     for (int i = 0; i < 2; ++i) {
+        if (aev_in_[i]) (void) hipEventDestroy(aev_in_[i]);
+        if (aev_done_[i]) (void) hipEventDestroy(aev_done_[i]);
+        if (aev_out_[i]) (void) hipEventDestroy(aev_out_[i]);
         if (ev_in_[i]) (void) hipEventDestroy(ev_in_[i]);
         if (ev_done_[i]) (void) hipEventDestroy(ev_done_[i]);
         if (ev_out_[i]) (void) hipEventDestroy(ev_out_[i]);
@@ -650,6 +664,7 @@ bool Engine::profile_read(double *ms, int64_t *launches, std::string *err) {
 }
 
 bool Engine::synchronize(std::string *err) {
+    if ((async_busy_[0] || async_busy_[1]) && !drain_async(err)) return false;
     if (hipStreamSynchronize(stream_) != hipSuccess) {
         *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
         return false;
@@ -659,6 +674,7 @@ bool Engine::synchronize(std::string *err) {
 
 bool Engine::reset(const uint8_t *host_mask, std::string *err) {
     (void) hipSetDevice(device_);
+    // (the reset kernel is ordered behind every enqueued call on the handle's stream; nothing to drain)
     ResetArgs r;
     r.hist = d_hist_[0];
     r.hist2 = d_hist_[1];
@@ -1248,8 +1264,90 @@ bool Engine::process_host_pipelined(int T, const int16_t *pcm, int16_t *out, boo
     return true;
 }
 
+bool Engine::drain_async(std::string *err) {
+    bool ok = true;
+    for (int s = 0; s < 2; ++s) {
+        if (!async_busy_[s]) continue;
+        if (hipEventSynchronize(aev_out_[s]) != hipSuccess) ok = false;
+        async_busy_[s] = false;
+    }
+    if (!ok) {
+        *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
+        (void) hipDeviceSynchronize();
+    }
+    return ok;
+}
+
+// One asynchronous host call = H2D on copy_in_, the kernels on the handle's stream, D2H on copy_out_, chained by events; consecutive
+// calls alternate between two slots of device staging, so call n + 1's copy-in and call n - 1's copy-out run under call n's kernels
+// (the link carries ~48 GB/s each way at once, profiles/r05_pcie_probe.txt: 2.8 ms per 4096 x 64 frames, the kernels 2.6 ms).  A
+// synchronous call of that size cannot hide its first copy-in and last copy-out and has to cut its kernels into short, less efficient
+// sub-chunks to overlap anything at all (process_host_pipelined).
+bool Engine::process_host_async(int T, const int16_t *pcm, int16_t *out, std::string *err) {
+    (void) hipSetDevice(device_);
+    if (pointer_kind(pcm) != kPtrPinned || pointer_kind(out) != kPtrPinned) {
+        *err = "asynchronous host calls need page-locked `pcm` and `enhanced` (pv_koala_batch_host_alloc, hipHostMalloc or hipHostRegister).";
+        return false;
+    }
+    const size_t bytes = (size_t) B_ * T * kFrame * 2;
+    {
+        const char *pa = (const char *) pcm, *pb = (const char *) out;
+        if (pa != pb && pa < pb + bytes && pb < pa + bytes) {
+            *err = "`pcm` and `enhanced` overlap partially.";
+            return false;
+        }
+    }
+    if (!aev_in_[0]) {
+        bool ok = true;
+        for (int i = 0; i < 2 && ok; ++i)
+            ok = hipEventCreateWithFlags(&aev_in_[i], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&aev_done_[i], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&aev_out_[i], hipEventDisableTiming) == hipSuccess;
+        if (ok) {
+            d_in2_ = (int16_t *) dalloc((size_t) B_ * Tmax_ * kFrame * 2, false);
+            d_out2_ = (int16_t *) dalloc((size_t) B_ * Tmax_ * kFrame * 2, false);
+            ok = d_in2_ && d_out2_;
+        }
+        if (!ok) {
+            (void) hipGetLastError();
+            *err = "Failed to allocate the second staging slot of asynchronous host calls.";
+            return false;
+        }
+    }
+    const int s = (int) (async_n_ & 1u);
+    if (async_busy_[s]) {  // the call two back: its copy-out frees this slot (and is the flow control)
+        if (hipEventSynchronize(aev_out_[s]) != hipSuccess) {
+            *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
+            return false;
+        }
+        async_busy_[s] = false;
+    }
+    int16_t *din = s ? d_in2_ : d_in_, *dout = s ? d_out2_ : d_out_;
+    bool ok = hipMemcpyAsync(din, pcm, bytes, hipMemcpyHostToDevice, copy_in_) == hipSuccess;
+    ok = ok && hipEventRecord(aev_in_[s], copy_in_) == hipSuccess;
+    ok = ok && hipStreamWaitEvent(stream_, aev_in_[s], 0) == hipSuccess;
+    if (!ok) {
+        *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
+        return false;
+    }
+    if (!run_device(T, din, dout, err)) return false;
+    ok = hipEventRecord(aev_done_[s], stream_) == hipSuccess;
+    ok = ok && hipStreamWaitEvent(copy_out_, aev_done_[s], 0) == hipSuccess;
+    ok = ok && hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, copy_out_) == hipSuccess;
+    ok = ok && hipEventRecord(aev_out_[s], copy_out_) == hipSuccess;
+    if (!ok) {
+        *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
+        (void) hipDeviceSynchronize();
+        return false;
+    }
+    async_busy_[s] = true;
+    ++async_n_;
+    return true;
+}
+
 bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err, bool host_pointers) {
     (void) hipSetDevice(device_);
+    if ((async_busy_[0] || async_busy_[1]) && !drain_async(err)) return false;
     const size_t bytes = (size_t) B_ * T * kFrame * 2;
     // (the single-stream ABI takes host buffers by contract: no driver query per frame on the latency path)
     const PointerKind kin = host_pointers ? kPtrPageable : pointer_kind(pcm), kout = host_pointers ? kPtrPageable : pointer_kind(out);
@@ -1294,6 +1392,9 @@ bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err, 
                 ok = zero_copy || hipMemcpyAsync(d_in_, h_in_, bytes, hipMemcpyHostToDevice, stream_) == hipSuccess;
                 ok = ok && run_device(1, zero_copy ? h_in_ : d_in_, zero_copy ? h_out_ : d_out_, err);
                 ok = ok && (zero_copy || hipMemcpyAsync(h_out_, d_out_, bytes, hipMemcpyDeviceToHost, stream_) == hipSuccess);
+                // zero-copy frames end with the completion word (the output is already in host memory when that node runs)
+                frame_graph_signals_[parity] = ok && zero_copy && spin_wait_ && h_frame_word_ && d_frame_count_;
+                if (frame_graph_signals_[parity]) launch_frame_done(d_frame_count_, h_frame_word_, stream_);
                 ok = (hipStreamEndCapture(stream_, &graph) == hipSuccess) && ok;
                 ok = ok && hipGraphInstantiate(&frame_graph_[parity], graph, nullptr, nullptr, 0) == hipSuccess;
                 if (graph) (void) hipGraphDestroy(graph);
@@ -1310,7 +1411,31 @@ bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err, 
         if (use_graph_) {
             if (hipGraphLaunch(frame_graph_[parity], stream_) != hipSuccess) goto fail;
             hs_cur_ = hs ^ 1;
-            if (hipStreamSynchronize(stream_) != hipSuccess) goto fail;
+            if (frame_graph_signals_[parity]) {
+                // Spin on the frame's completion word (a frame takes 60-100 us: longer than the runtime's own active-wait window,
+                // after which hipStreamSynchronize sleeps on an interrupt and wakes up whenever the host scheduler gets to it).
+                // Bounded: a frame that has not reported after 20 ms is handed to hipStreamSynchronize, which also surfaces errors.
+                const unsigned want = ++frame_seq_;
+                const auto t0 = std::chrono::steady_clock::now();
+                bool seen = false;
+                for (unsigned spins = 0;; ++spins) {
+                    if (__atomic_load_n(h_frame_word_, __ATOMIC_ACQUIRE) == want) {
+                        seen = true;
+                        break;
+                    }
+                    __builtin_ia32_pause();
+                    if ((spins & 0x3ff) == 0x3ff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+                }
+                if (!seen) {
+                    if (hipStreamSynchronize(stream_) != hipSuccess) goto fail;
+                    frame_seq_ = __atomic_load_n(h_frame_word_, __ATOMIC_ACQUIRE);  // (resynchronise the expectation)
+                } else if ((want & 63u) == 0) {
+                    // (now and then: lets the runtime retire the launches it has been tracking; returns at once, the stream is idle)
+                    if (hipStreamSynchronize(stream_) != hipSuccess) goto fail;
+                }
+            } else if (hipStreamSynchronize(stream_) != hipSuccess) {
+                goto fail;
+            }
             memcpy(out, h_out_, bytes);
             return true;
         }

@@ -43,6 +43,12 @@ public:
 
     // pcm/out: [B][T*256]; host or device pointers (both of the same kind).  Host: synchronous.  Device: enqueued.
     bool process(int T, const int16_t *pcm, int16_t *out, std::string *err, bool host_pointers = false);
+    // Page-locked host buffers, asynchronous: the call's copy-in, kernels and copy-out are enqueued on three streams and the function
+    // returns; up to two such calls are in flight (a third first waits for the oldest), so the copies of one call run under the
+    // kernels of its neighbours.  `drain_async` (also reached through synchronize(), and entered by every other entry point) waits
+    // for all of them.
+    bool process_host_async(int T, const int16_t *pcm, int16_t *out, std::string *err);
+    bool drain_async(std::string *err);
     bool reset(const uint8_t *host_mask, std::string *err);
     void set_stream(hipStream_t s) { stream_ = s ? s : own_stream_; }
     bool synchronize(std::string *err);
@@ -107,6 +113,11 @@ private:
     GruWaveItem wave_item(int i, int t, int mtb) const;
     bool wave_fits() const;
     void run_wave(int T, int mtb);
+    // asynchronous host calls: two slots of full-size device staging (slot 0 = d_in_ / d_out_, slot 1 allocated on first use)
+    int16_t *d_in2_ = nullptr, *d_out2_ = nullptr;
+    hipEvent_t aev_in_[2] = {nullptr, nullptr}, aev_done_[2] = {nullptr, nullptr}, aev_out_[2] = {nullptr, nullptr};
+    bool async_busy_[2] = {false, false};
+    unsigned async_n_ = 0;
     hipStream_t copy_in_ = nullptr, copy_out_ = nullptr;
     hipEvent_t ev_in_[2] = {nullptr, nullptr}, ev_done_[2] = {nullptr, nullptr}, ev_out_[2] = {nullptr, nullptr};
     int host_chunk_ = 1;
@@ -114,6 +125,12 @@ private:
 
     // hipGraph of one host-pointer frame (copy-in, 23 kernels, copy-out); built on first use
     hipGraphExec_t frame_graph_[8] = {};  // one per combination of the hidden-state / history / tail ping-pong indices
+    // completion word of the zero-copy one-frame replays (kns_stft.hip, frame_done_kernel): the host spins on a word in page-locked
+    // memory instead of sleeping in hipStreamSynchronize, whose wake-up is what made p99 drift away from p50 on a busy host
+    unsigned *d_frame_count_ = nullptr, *h_frame_word_ = nullptr;
+    unsigned frame_seq_ = 0;
+    bool frame_graph_signals_[8] = {};
+    bool spin_wait_ = true;
     bool use_graph_ = true, no_small_ = false, no_zero_copy_ = false, no_recompute_ = false, debug_taps_ = false;
     // developer switches (all read once in init() through dev_env(): compiled out of the product library)
     int dev_variant_ = 0, dev_only_class_ = -1, dev_analysis_seg_ = 0, dev_synth_seg_ = 0, dev_small_mt_ = 0, dev_steps_mt_ = 192, dev_wave_mt_ = -1, dev_wave_group_ = 0, dev_wave_parts_ = 1;

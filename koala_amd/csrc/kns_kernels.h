@@ -224,5 +224,7 @@ struct ResetArgs {
     int fhist_frames = 0, nbf = 0;
 };
 void launch_reset(const ResetArgs &a, hipStream_t s);
+// last node of a captured one-frame replay: ++*counter (device memory), published to *host_word (page-locked host memory)
+void launch_frame_done(unsigned *counter, unsigned *host_word, hipStream_t s);
 
 }  // namespace kns

@@ -508,6 +508,19 @@ __global__ void reset_kernel(ResetArgs g) {
     }
 }
 
+// ---- completion word of a one-frame graph replay: the last node of the captured frame.  Counts the replays on the device and
+// publishes the count to a word in page-locked host memory with a system-scope release: a host that sees the count sees the frame's
+// output (written to host memory by the synthesis kernel, complete at the kernel boundary before this node runs).
+__global__ void frame_done_kernel(unsigned *counter, unsigned *host_word) {
+    const unsigned v = *counter + 1u;
+    *counter = v;
+    __hip_atomic_store(host_word, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+void launch_frame_done(unsigned *counter, unsigned *host_word, hipStream_t s) {
+    hipLaunchKernelGGL(frame_done_kernel, dim3(1), dim3(1), 0, s, counter, host_word);
+}
+
 void launch_reset(const ResetArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(reset_kernel, dim3(a.Bpad), dim3(256), 0, s, a);
 }

@@ -427,6 +427,32 @@ PV_API pv_status_t pv_koala_batch_process_chunk(pv_koala_batch_t *object, int32_
     });
 }
 
+PV_API pv_status_t pv_koala_batch_process_chunk_async(pv_koala_batch_t *object, int32_t num_frames, const int16_t *pcm,
+                                                      int16_t *enhanced) {
+    t_stack.clear();
+    if (!object) {
+        push_error(0x64, "Argument `object` is NULL.");
+        return PV_STATUS_INVALID_ARGUMENT;
+    }
+    if (!pcm || !enhanced) {
+        push_error(0x64, "Argument `%s` is NULL.", pcm ? "enhanced" : "pcm");
+        return PV_STATUS_INVALID_ARGUMENT;
+    }
+    if (num_frames <= 0 || num_frames > object->engine->max_frames()) {
+        push_error(0x66, "`num_frames` %d is outside [1, %d].", num_frames, object->engine->max_frames());
+        return PV_STATUS_INVALID_ARGUMENT;
+    }
+    return guarded([&] {
+        std::string err;
+        if (!object->engine->process_host_async(num_frames, pcm, enhanced, &err)) {
+            push_error(0x33A, "%s", err.c_str());
+            push_error(0x12C, "Picovoice Error.");
+            return PV_STATUS_RUNTIME_ERROR;
+        }
+        return PV_STATUS_SUCCESS;
+    });
+}
+
 PV_API pv_status_t pv_koala_batch_process(pv_koala_batch_t *object, const int16_t *pcm, int16_t *enhanced) {
     return pv_koala_batch_process_chunk(object, 1, pcm, enhanced);
 }

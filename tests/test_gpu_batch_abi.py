@@ -140,3 +140,43 @@ def test_overlapping_host_buffers_are_refused_where_the_call_is_pipelined(lib, r
     assert lib.pv_koala_batch_process_chunk(h, 4, s.ctypes.data, s.ctypes.data) == SUCCESS
     assert np.array_equal(s, expect)
     lib.pv_koala_batch_delete(h)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_asynchronous_host_calls_equal_the_synchronous_path(random_model, precision):
+    """pv_koala_batch_process_chunk_async: two calls in flight, copies under the neighbours' kernels -- the same samples, bit for bit,
+    as the same calls made synchronously; calls of different lengths, an in-place call, a reset and a synchronous call in between."""
+    B, Tmax = 70, 12
+    ka = koala_amd.create_batch('key', B, Tmax, precision, model_path=random_model)
+    ks = koala_amd.create_batch('key', B, Tmax, precision, model_path=random_model)
+    lens = [12, 5, 12, 1, 7, 12, 3]
+    xs = [synth_streams(B, t, seed=900 + i) for i, t in enumerate(lens)]
+    want = []
+    for i, x in enumerate(xs):
+        if i == 4:
+            ks.reset()
+        want.append(ks.process(x))
+    bufs = [(ka.alloc_host(Tmax), ka.alloc_host(Tmax)) for _ in range(len(lens))]
+    got = []
+    for i, (x, t) in enumerate(zip(xs, lens)):
+        a, b = bufs[i]
+        # contiguous [B, t * 256] windows at the head of the page-locked buffers
+        ain = np.frombuffer(a.reshape(-1), np.int16, B * t * 256).reshape(B, t * 256)
+        aout = ain if i == 2 else np.frombuffer(b.reshape(-1), np.int16, B * t * 256).reshape(B, t * 256)
+        ain[:] = x
+        if i == 4:
+            ka.reset()
+        if i == 5:  # a synchronous call in between first waits for the two in flight
+            aout[:] = ka.process(x)
+        else:
+            ka.process_async(ain, aout)
+        got.append(aout)
+    ka.synchronize()
+    for i in range(len(lens)):
+        assert np.array_equal(got[i], want[i]), i
+    # pageable buffers are refused, nothing is processed, the message is on the stack
+    x = synth_streams(B, 2, seed=1)
+    with pytest.raises(koala_amd.KoalaError):
+        ka.process_async(x, np.empty_like(x))
+    ka.delete()
+    ks.delete()
