@@ -331,23 +331,23 @@ def extra_points(args, torch, np, koala_amd, model, kb, x, dx, dy, base, local_r
     dt = time_steps(lambda: kb.process_into(px, py), lambda: None, 4, 1)
     out['host_pinned'] = {'workload': '%d x %d frames per call, caller buffers page-locked (pv_koala_batch_host_alloc), synchronous calls'
                                       % (B, T), 'frames_per_s': round(B * T * 4 / dt, 1)}
-    # ... and the throughput-oriented caller: two page-locked buffer pairs, pv_koala_batch_process_chunk_async -- one call's copies run
+    # ... and the throughput-oriented caller: three page-locked buffer pairs, pv_koala_batch_process_chunk_async -- one call's copies run
     # under its neighbours' kernels (a synchronous call cannot hide its first copy-in and last copy-out).  (engine on its own stream
     # here: the asynchronous path chains three streams by events)
     try:
         ka = koala_amd.create_batch('bench', B, T, args.precision, model_path=model, device=dev, library_path=args.library)
-        pairs = [(ka.alloc_host(T), ka.alloc_host(T)) for _ in range(2)]
+        pairs = [(ka.alloc_host(T), ka.alloc_host(T)) for _ in range(3)]
         for a, _ in pairs:
             a[:] = x
         n_async = [0]
 
         def async_step():
-            a, b = pairs[n_async[0] & 1]
+            a, b = pairs[n_async[0] % 3]
             ka.process_async(a, b)
             n_async[0] += 1
         dt = time_steps(async_step, ka.synchronize, 12, 3)
-        out['host_pinned_async'] = {'workload': '%d x %d frames per call, two page-locked buffer pairs alternating, '
-                                                'pv_koala_batch_process_chunk_async (two calls in flight)' % (B, T),
+        out['host_pinned_async'] = {'workload': '%d x %d frames per call, three page-locked buffer pairs in rotation, '
+                                                'pv_koala_batch_process_chunk_async (three calls in flight)' % (B, T),
                                     'frames_per_s': round(B * T * 12 / dt, 1)}
         ka.delete()
     except Exception as e:  # (a library without the entry point: developer A/B runs against older builds)

@@ -47,10 +47,11 @@ PV_API pv_status_t pv_koala_batch_process_chunk(pv_koala_batch_t *object, int32_
 
 /* The same for a throughput-oriented host caller (a many-files batch job that double-buffers its I/O): `pcm` and `enhanced` must be
  * PAGE-LOCKED host memory (pv_koala_batch_host_alloc, hipHostMalloc, hipHostRegister; anything else is refused with
- * PV_STATUS_RUNTIME_ERROR, nothing processed).  The call enqueues its copy-in, kernels and copy-out and RETURNS; up to two such calls are
- * in flight per handle (a third first waits for the oldest), so one call's copies run under its neighbours' kernels -- a synchronous
+ * PV_STATUS_RUNTIME_ERROR, nothing processed).  The call enqueues its copy-in, kernels and copy-out and RETURNS; up to three such calls are
+ * in flight per handle (a fourth first waits for the oldest), so one call's copies run under its neighbours' kernels -- a synchronous
  * call cannot hide its first copy-in and last copy-out.  Calls complete in order; `enhanced` of a call is valid, and `pcm` may be
- * reused, once pv_koala_batch_synchronize() has returned or two further asynchronous calls have been accepted.  Every other entry
+ * reused, once pv_koala_batch_synchronize() has returned or three further asynchronous calls have been accepted (a caller rotating
+ * over three buffer pairs keeps both directions of the link and the GPU busy at once).  Every other entry
  * point of the handle first waits for the calls in flight.  `enhanced` may equal `pcm`. */
 PV_API pv_status_t pv_koala_batch_process_chunk_async(pv_koala_batch_t *object, int32_t num_frames, const int16_t *pcm,
                                                       int16_t *enhanced);

@@ -101,9 +101,9 @@ class KoalaBatch(object):
                                                            pcm.ctypes.data, enhanced.ctypes.data), 'Processing failed')
 
     def process_async(self, pcm: np.ndarray, enhanced: np.ndarray) -> None:
-        """`process_into()` without the wait, for page-locked arrays (`alloc_host()`): the call is enqueued and returns; up to two are
-        in flight, so a caller that alternates between two buffer pairs keeps the link and the GPU busy at once.  `enhanced` is valid
-        after `synchronize()` (or once two further asynchronous calls have been accepted)."""
+        """`process_into()` without the wait, for page-locked arrays (`alloc_host()`): the call is enqueued and returns; up to three are
+        in flight, so a caller that rotates over three buffer pairs keeps the link and the GPU busy at once.  `enhanced` is valid
+        after `synchronize()` (or once three further asynchronous calls have been accepted)."""
         for a in (pcm, enhanced):
             if (not isinstance(a, np.ndarray) or a.dtype != np.int16 or not a.flags['C_CONTIGUOUS'] or a.ndim != 2 or
                     a.shape[0] != self.num_streams or a.shape[1] % self.frame_length or a.shape != pcm.shape):

@@ -593,10 +593,11 @@ Engine::~Engine() {
     if (h_frame_word_) (void) hipHostFree(h_frame_word_);
     if (h_in_) (void) hipHostFree(h_in_);
     if (h_out_) (void) hipHostFree(h_out_);
+    for (int i = 0; i < 4; ++i)
+        if (aev_out_[i]) (void) hipEventDestroy(aev_out_[i]);
     for (int i = 0; i < 2; ++i) {
         if (aev_in_[i]) (void) hipEventDestroy(aev_in_[i]);
         if (aev_done_[i]) (void) hipEventDestroy(aev_done_[i]);
-        if (aev_out_[i]) (void) hipEventDestroy(aev_out_[i]);
         if (ev_in_[i]) (void) hipEventDestroy(ev_in_[i]);
         if (ev_done_[i]) (void) hipEventDestroy(ev_done_[i]);
         if (ev_out_[i]) (void) hipEventDestroy(ev_out_[i]);
@@ -664,7 +665,7 @@ bool Engine::profile_read(double *ms, int64_t *launches, std::string *err) {
 }
 
 bool Engine::synchronize(std::string *err) {
-    if ((async_busy_[0] || async_busy_[1]) && !drain_async(err)) return false;
+    if (async_n_ && !drain_async(err)) return false;
     if (hipStreamSynchronize(stream_) != hipSuccess) {
         *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
         return false;
@@ -1266,10 +1267,10 @@ bool Engine::process_host_pipelined(int T, const int16_t *pcm, int16_t *out, boo
 
 bool Engine::drain_async(std::string *err) {
     bool ok = true;
-    for (int s = 0; s < 2; ++s) {
-        if (!async_busy_[s]) continue;
-        if (hipEventSynchronize(aev_out_[s]) != hipSuccess) ok = false;
-        async_busy_[s] = false;
+    for (int i = 0; i < 4; ++i) {
+        if (!async_busy_[i]) continue;
+        if (hipEventSynchronize(aev_out_[i]) != hipSuccess) ok = false;
+        async_busy_[i] = false;
     }
     if (!ok) {
         *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
@@ -1278,11 +1279,13 @@ bool Engine::drain_async(std::string *err) {
     return ok;
 }
 
-// One asynchronous host call = H2D on copy_in_, the kernels on the handle's stream, D2H on copy_out_, chained by events; consecutive
-// calls alternate between two slots of device staging, so call n + 1's copy-in and call n - 1's copy-out run under call n's kernels
-// (the link carries ~48 GB/s each way at once, profiles/r05_pcie_probe.txt: 2.8 ms per 4096 x 64 frames, the kernels 2.6 ms).  A
-// synchronous call of that size cannot hide its first copy-in and last copy-out and has to cut its kernels into short, less efficient
-// sub-chunks to overlap anything at all (process_host_pipelined).
+// One asynchronous host call = H2D on copy_in_, the kernels on the handle's stream, D2H on copy_out_, chained by events.  Up to
+// THREE calls are in flight: with two, a caller alternating between two buffer pairs cannot issue call n + 2 before call n's copy-out has
+// finished, which puts a slot's copy-in, kernels and copy-out in series (measured: 4.03 ms per 4096 x 64 frames = (2.8 + 2.6 + 2.8) / 2);
+// with three, the link works in both directions under the kernels (~48 GB/s each way at once, profiles/r05_pcie_probe.txt).  Device
+// staging alternates between two slots: the input half of slot s is free once the kernels of call n - 2 have read it, the output half
+// once call n - 2's copy-out has -- both waited for on the device, by the stream that needs it.  A synchronous call of that size cannot
+// hide its first copy-in and last copy-out and has to cut its kernels into short, less efficient sub-chunks (process_host_pipelined).
 bool Engine::process_host_async(int T, const int16_t *pcm, int16_t *out, std::string *err) {
     (void) hipSetDevice(device_);
     if (pointer_kind(pcm) != kPtrPinned || pointer_kind(out) != kPtrPinned) {
@@ -1297,12 +1300,12 @@ bool Engine::process_host_async(int T, const int16_t *pcm, int16_t *out, std::st
             return false;
         }
     }
-    if (!aev_in_[0]) {
+    if (!aev_out_[0]) {
         bool ok = true;
+        for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreateWithFlags(&aev_out_[i], hipEventDisableTiming) == hipSuccess;
         for (int i = 0; i < 2 && ok; ++i)
             ok = hipEventCreateWithFlags(&aev_in_[i], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&aev_done_[i], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&aev_out_[i], hipEventDisableTiming) == hipSuccess;
+                 hipEventCreateWithFlags(&aev_done_[i], hipEventDisableTiming) == hipSuccess;
         if (ok) {
             d_in2_ = (int16_t *) dalloc((size_t) B_ * Tmax_ * kFrame * 2, false);
             d_out2_ = (int16_t *) dalloc((size_t) B_ * Tmax_ * kFrame * 2, false);
@@ -1314,18 +1317,22 @@ bool Engine::process_host_async(int T, const int16_t *pcm, int16_t *out, std::st
             return false;
         }
     }
-    const int s = (int) (async_n_ & 1u);
-    if (async_busy_[s]) {  // the call two back: its copy-out frees this slot (and is the flow control)
-        if (hipEventSynchronize(aev_out_[s]) != hipSuccess) {
+    const unsigned n = async_n_;
+    const int s = (int) (n & 1u), ring = (int) (n & 3u), ring3 = (int) ((n - 3u) & 3u), ring2 = (int) ((n - 2u) & 3u);
+    if (n >= 3 && async_busy_[ring3]) {  // the window: the call three back has completed before this one is accepted
+        if (hipEventSynchronize(aev_out_[ring3]) != hipSuccess) {
             *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
             return false;
         }
-        async_busy_[s] = false;
+        async_busy_[ring3] = false;
     }
     int16_t *din = s ? d_in2_ : d_in_, *dout = s ? d_out2_ : d_out_;
-    bool ok = hipMemcpyAsync(din, pcm, bytes, hipMemcpyHostToDevice, copy_in_) == hipSuccess;
+    bool ok = true;
+    if (n >= 2) ok = hipStreamWaitEvent(copy_in_, aev_done_[s], 0) == hipSuccess;  // the kernels of call n - 2 have read this slot's input
+    ok = ok && hipMemcpyAsync(din, pcm, bytes, hipMemcpyHostToDevice, copy_in_) == hipSuccess;
     ok = ok && hipEventRecord(aev_in_[s], copy_in_) == hipSuccess;
     ok = ok && hipStreamWaitEvent(stream_, aev_in_[s], 0) == hipSuccess;
+    if (n >= 2) ok = ok && hipStreamWaitEvent(stream_, aev_out_[ring2], 0) == hipSuccess;  // ... and its copy-out this slot's output
     if (!ok) {
         *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
         return false;
@@ -1334,20 +1341,20 @@ bool Engine::process_host_async(int T, const int16_t *pcm, int16_t *out, std::st
     ok = hipEventRecord(aev_done_[s], stream_) == hipSuccess;
     ok = ok && hipStreamWaitEvent(copy_out_, aev_done_[s], 0) == hipSuccess;
     ok = ok && hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, copy_out_) == hipSuccess;
-    ok = ok && hipEventRecord(aev_out_[s], copy_out_) == hipSuccess;
+    ok = ok && hipEventRecord(aev_out_[ring], copy_out_) == hipSuccess;
     if (!ok) {
         *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
         (void) hipDeviceSynchronize();
         return false;
     }
-    async_busy_[s] = true;
+    async_busy_[ring] = true;
     ++async_n_;
     return true;
 }
 
 bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err, bool host_pointers) {
     (void) hipSetDevice(device_);
-    if ((async_busy_[0] || async_busy_[1]) && !drain_async(err)) return false;
+    if (async_n_ && !drain_async(err)) return false;
     const size_t bytes = (size_t) B_ * T * kFrame * 2;
     // (the single-stream ABI takes host buffers by contract: no driver query per frame on the latency path)
     const PointerKind kin = host_pointers ? kPtrPageable : pointer_kind(pcm), kout = host_pointers ? kPtrPageable : pointer_kind(out);
@@ -1429,7 +1436,7 @@ bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err, 
                 if (!seen) {
                     if (hipStreamSynchronize(stream_) != hipSuccess) goto fail;
                     frame_seq_ = __atomic_load_n(h_frame_word_, __ATOMIC_ACQUIRE);  // (resynchronise the expectation)
-                } else if ((want & 63u) == 0) {
+                } else if ((want & 1023u) == 0) {
                     // (now and then: lets the runtime retire the launches it has been tracking; returns at once, the stream is idle)
                     if (hipStreamSynchronize(stream_) != hipSuccess) goto fail;
                 }

@@ -44,7 +44,7 @@ public:
     // pcm/out: [B][T*256]; host or device pointers (both of the same kind).  Host: synchronous.  Device: enqueued.
     bool process(int T, const int16_t *pcm, int16_t *out, std::string *err, bool host_pointers = false);
     // Page-locked host buffers, asynchronous: the call's copy-in, kernels and copy-out are enqueued on three streams and the function
-    // returns; up to two such calls are in flight (a third first waits for the oldest), so the copies of one call run under the
+    // returns; up to three such calls are in flight (a fourth first waits for the oldest), so the copies of one call run under the
     // kernels of its neighbours.  `drain_async` (also reached through synchronize(), and entered by every other entry point) waits
     // for all of them.
     bool process_host_async(int T, const int16_t *pcm, int16_t *out, std::string *err);
@@ -115,8 +115,8 @@ private:
     void run_wave(int T, int mtb);
     // asynchronous host calls: two slots of full-size device staging (slot 0 = d_in_ / d_out_, slot 1 allocated on first use)
     int16_t *d_in2_ = nullptr, *d_out2_ = nullptr;
-    hipEvent_t aev_in_[2] = {nullptr, nullptr}, aev_done_[2] = {nullptr, nullptr}, aev_out_[2] = {nullptr, nullptr};
-    bool async_busy_[2] = {false, false};
+    hipEvent_t aev_in_[2] = {nullptr, nullptr}, aev_done_[2] = {nullptr, nullptr}, aev_out_[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool async_busy_[4] = {false, false, false, false};  // by call number mod 4: the window is three calls
     unsigned async_n_ = 0;
     hipStream_t copy_in_ = nullptr, copy_out_ = nullptr;
     hipEvent_t ev_in_[2] = {nullptr, nullptr}, ev_done_[2] = {nullptr, nullptr}, ev_out_[2] = {nullptr, nullptr};

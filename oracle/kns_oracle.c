@@ -118,6 +118,15 @@ float kns_tanh(float x) {
     return copysignf(v, x);
 }
 
+/* ---- bf16 mode (round 5): the transcendentals of the tolerance-specified configuration are the CORRECTLY ROUNDED functions 2^x and
+ * log2 x (via double precision; 1 / x already is IEEE division), evaluated in the engine's operation order -- gates: 1 / (1 + 2^y) on the
+ * pre-scaled pre-activations; heads: 1 / (1 + 2^(x * -log2 e)); features: log2(P) * ln 2.  The hardware's v_exp_f32 / v_log_f32 /
+ * v_rcp_f32 are within one ulp of those, so the two sides now differ only where the hardware is not correctly rounded; rounds 1-4
+ * used the fp32 mode's polynomials here (1-2 ulp off in their own direction, and e^(y ln 2) carries |y| ulps of the product's
+ * rounding), which doubled the distance for no reason.  The fp32 mode keeps the polynomials: it is bit-comparable with the GPU. */
+static inline float kns_exp2_cr(float y) { return (float) exp2((double) y); }
+static inline float kns_log2_cr(float x) { return (float) log2((double) x); }
+
 /* ---- sensitivity probe (KNS_ORACLE_JITTER=<seed>, bf16 mode only; tools/model_sensitivity.py).  The bf16 configuration is
  * specified to a tolerance: a second valid implementation (the GPU: hardware 2^x / 1/x / log2, an MFMA that sums eight products
  * before it rounds -- profiles/r05_mfma_probe.txt) differs from this restatement in the last bit of a transcendental or a GEMM
@@ -485,13 +494,19 @@ static void spectrum512(const kns_params_t *p, const int16_t *hist, const int16_
     spec[2 * 256 + 1] = 0.0f;
 }
 
+/* ln of the power + 1e-10: the spec's polynomial in the fp32 mode; in the bf16 mode the engine's log2(x) * ln 2 with the correctly
+ * rounded log2 (kns_log2_cr above) */
+static inline float feature_log(const kns_params_t *p, float x) {
+    return p->precision == KNS_PREC_BF16 ? kns_log2_cr(x) * 0.693147180559945309f : kns_log(x);
+}
+
 static void analysis(const kns_params_t *p, const int16_t *hist, const int16_t *pcm, float *spec, float *feat) {
     spectrum512(p, hist, pcm, spec);
     for (int k = 0; k < KNS_BINS; ++k) {
         const float re = spec[2 * k], im = spec[2 * k + 1];
         float pw = fmaf(re, re, im * im);
         if (k == 0 || k == KNS_BINS - 1) pw = re * re;
-        feat[k] = (kns_log(pw + 1e-10f) - p->mean[k]) * p->scale[k];
+        feat[k] = (feature_log(p, pw + 1e-10f) - p->mean[k]) * p->scale[k];
     }
 }
 
@@ -632,6 +647,21 @@ struct kns_oracle {
  * loops blocked for registers and caches (selected unless KNS_ORACLE_SIMPLE_GEMM is set in the environment). */
 static void gemm_block_simple(int nb, const float *x, int ldx, int K, const float *w, int N, const float *bias, float *acc,
                               int lda, int round_x, int bias_first) {
+    if (round_x) { /* bf16 operands: the bf16 MFMA's arithmetic -- sums of eight products, one rounding per group (gemm_block_g8 below
+                    * is the same statement with the loops arranged for AVX2) */
+        for (int s = 0; s < nb; ++s)
+            for (int n = 0; n < N; ++n) {
+                float v = 0.0f;
+                for (int k0 = 0; k0 < K; k0 += 8) {
+                    double sum = 0.0;
+                    for (int k = k0; k < K && k < k0 + 8; ++k)
+                        sum += (double) kns_round_bf16(x[(size_t) s * ldx + k]) * (double) w[(size_t) k * N + n];
+                    v = (float) ((double) v + sum);
+                }
+                acc[(size_t) s * lda + n] = v + bias[n];
+            }
+        return;
+    }
     for (int s = 0; s < nb; ++s) {
         if (bias_first)
             memcpy(acc + (size_t) s * lda, bias, sizeof(float) * (size_t) N);
@@ -688,6 +718,49 @@ KNS_PANEL_KERNEL(4)
 KNS_PANEL_KERNEL(5)
 KNS_PANEL_KERNEL(6)
 
+/* bf16 mode (round 5): what v_mfma_f32_16x16x32_bf16 computes, as measured on the device (profiles/r05_mfma_probe.txt,
+ * tools/microbench/mfma_probe.hip) -- NOT an fmaf chain: the products of EIGHT consecutive k (one lane group's fragment) are summed
+ * without intermediate rounding and added to the accumulator with ONE round-to-nearest-even, group after group in ascending k.
+ * Restated with the group sum in double precision: a product of two bf16 values is exact there, eight of them add exactly unless
+ * their exponents spread over more than ~34 bits (the hardware truncates such addends itself), and acc + sum rounds once to fp32.
+ * Against the device this agrees on 99.7 % of the outputs of uniform random data (the fmaf chain: 90.6 %).  Groups are counted from
+ * k = 0 of the operand as the engine packs it; every segment of a stage input starts at a multiple of 8 (0, 40, 257 + ...: the y part
+ * in front is 40 wide, the narrow ones ride behind the features), so logical and packed groups coincide.  Bias after the chain. */
+static void gemm_block_g8(int nb, const float *x, int ldx, int K, const float *w, int N, const float *bias, float *acc, int lda) {
+    const int n8 = N & ~7;
+    for (int s = 0; s < nb; ++s) {
+        const float *xs = x + (size_t) s * ldx;
+        float *a = acc + (size_t) s * lda;
+        for (int n0 = 0; n0 < n8; n0 += 8) {
+            __m256 av = _mm256_setzero_ps();
+            for (int k0 = 0; k0 < K; k0 += 8) {
+                const int k1 = k0 + 8 < K ? k0 + 8 : K;
+                __m256d lo = _mm256_setzero_pd(), hi = _mm256_setzero_pd();
+                for (int k = k0; k < k1; ++k) {
+                    const __m256d xb = _mm256_set1_pd((double) xs[k]);
+                    const __m256 wr = _mm256_loadu_ps(w + (size_t) k * N + n0);
+                    lo = _mm256_fmadd_pd(xb, _mm256_cvtps_pd(_mm256_castps256_ps128(wr)), lo); /* (exact products: fused or not, the same) */
+                    hi = _mm256_fmadd_pd(xb, _mm256_cvtps_pd(_mm256_extractf128_ps(wr, 1)), hi);
+                }
+                lo = _mm256_add_pd(lo, _mm256_cvtps_pd(_mm256_castps256_ps128(av)));
+                hi = _mm256_add_pd(hi, _mm256_cvtps_pd(_mm256_extractf128_ps(av, 1)));
+                av = _mm256_insertf128_ps(_mm256_castps128_ps256(_mm256_cvtpd_ps(lo)), _mm256_cvtpd_ps(hi), 1);
+            }
+            _mm256_storeu_ps(a + n0, _mm256_add_ps(av, _mm256_loadu_ps(bias + n0)));
+        }
+        for (int n = n8; n < N; ++n) {
+            float v = 0.0f;
+            for (int k0 = 0; k0 < K; k0 += 8) {
+                const int k1 = k0 + 8 < K ? k0 + 8 : K;
+                double sum = 0.0;
+                for (int k = k0; k < k1; ++k) sum += (double) xs[k] * (double) w[(size_t) k * N + n];
+                v = (float) ((double) v + sum);
+            }
+            a[n] = v + bias[n];
+        }
+    }
+}
+
 static int g_simple_gemm = -1;
 
 static void gemm_block_b(int nb, const float *x, int ldx, int K, const float *w, int N, const float *bias, float *acc,
@@ -704,6 +777,10 @@ static void gemm_block_b(int nb, const float *x, int ldx, int K, const float *w,
             for (int k = 0; k < K; ++k) xr[(size_t) s * K + k] = kns_round_bf16(x[(size_t) s * ldx + k]);
         x = xr;
         ldx = K;
+        /* bf16 operands: the bf16 MFMA's sums of eight (bias_first chains start from a zero "bias" in this mode) */
+        gemm_block_g8(nb, x, ldx, K, w, N, bias, acc, lda);
+        free(xr);
+        return;
     }
     typedef void (*panel_fn)(const float *, int, int, const float *, int, const float *, float *, int, int);
     static const panel_fn kernels[7] = {NULL, panel16_r1, panel16_r2, panel16_r3, panel16_r4, panel16_r5, panel16_r6};
@@ -821,21 +898,20 @@ static void gru_block(int nb, const float *x, int ldx, int K, const float *w_ih,
                 /* everything below lives in the pre-scaled domain (weights and biases carry -log2 e / 2 log2 e, scale_gates):
                  *   r = 1 / (1 + 2^(gi_r + gh_r))   z likewise   n = 1 - 2 / (1 + 2^(fma(r, gh_n, gi_n)))   h' = fma(z, h - n, n)
                  * (gh already holds b_hh: it rode in the recurrent GEMM)
-                 * -- the GPU's gate_block_bf16 (kns_device.hpp) with its hardware 2^x and reciprocal replaced by the spec's
-                 * polynomial exponential and an IEEE division */
+                 * -- the GPU's gate_block_bf16 (kns_device.hpp) with its hardware 2^x and reciprocal replaced by the correctly
+                 * rounded 2^x (kns_exp2_cr) and an IEEE division */
                 ir = kns_round_fp16(ir);
                 iz = kns_round_fp16(iz);
                 in = kns_round_fp16(in);
-                const float ln2 = 0.693147180559945309f;
                 float r, z, q;
                 if (jit_on) { /* sensitivity probe: a second implementation's last bits */
-                    r = jit(1.0f / (1.0f + jit(kns_exp((ir + ghs[j]) * ln2), 1)), 1);
-                    z = jit(1.0f / (1.0f + jit(kns_exp((iz + ghs[KNS_H + j]) * ln2), 1)), 1);
-                    q = jit(1.0f / (1.0f + jit(kns_exp(fmaf(r, ghs[2 * KNS_H + j], in) * ln2), 1)), 1);
+                    r = jit(1.0f / (1.0f + jit(kns_exp2_cr(ir + ghs[j]), 1)), 1);
+                    z = jit(1.0f / (1.0f + jit(kns_exp2_cr(iz + ghs[KNS_H + j]), 1)), 1);
+                    q = jit(1.0f / (1.0f + jit(kns_exp2_cr(fmaf(r, ghs[2 * KNS_H + j], in)), 1)), 1);
                 } else {
-                    r = 1.0f / (1.0f + kns_exp((ir + ghs[j]) * ln2));
-                    z = 1.0f / (1.0f + kns_exp((iz + ghs[KNS_H + j]) * ln2));
-                    q = 1.0f / (1.0f + kns_exp(fmaf(r, ghs[2 * KNS_H + j], in) * ln2));
+                    r = 1.0f / (1.0f + kns_exp2_cr(ir + ghs[j]));
+                    z = 1.0f / (1.0f + kns_exp2_cr(iz + ghs[KNS_H + j]));
+                    q = 1.0f / (1.0f + kns_exp2_cr(fmaf(r, ghs[2 * KNS_H + j], in)));
                 }
                 float n = fmaf(q, -2.0f, 1.0f);
                 float hp = h[s][j];
@@ -887,7 +963,7 @@ static void frame_block(const kns_params_t *p, int nb, kns_stream_t **st, const 
                 if (age <= st[s]->seen) {
                     memcpy(dst, st[s]->fhist[ht - age], sizeof(float) * KNS_BINS);
                 } else { /* before the stream began: the feature of a silent frame */
-                    for (int k = 0; k < KNS_BINS; ++k) dst[k] = (kns_log(1e-10f) - p->mean[k]) * p->scale[k];
+                    for (int k = 0; k < KNS_BINS; ++k) dst[k] = (feature_log(p, 1e-10f) - p->mean[k]) * p->scale[k];
                 }
             }
             memcpy(&w->fstack[s][(size_t) ht * KNS_BINS], w->feat[s], sizeof(float) * KNS_BINS);
@@ -932,7 +1008,13 @@ static void frame_block(const kns_params_t *p, int nb, kns_stream_t **st, const 
         gemm_block(nb, w->hx, KNS_H, KNS_H, g->w_head, g->d_out, g->b_head, &w->y[0][0], KNS_BINS, bf);
         for (int s = 0; s < nb; ++s)
             for (int j = 0; j < g->d_out; ++j) {
-                float v = kns_sigmoid(jit_on ? jit(w->y[s][j], 3) : w->y[s][j]);
+                float v;
+                if (bf) { /* the engine's head epilogue: 1 / (1 + 2^(x * -log2 e)) */
+                    const float xx = jit_on ? jit(w->y[s][j], 3) : w->y[s][j];
+                    v = 1.0f / (1.0f + kns_exp2_cr(xx * -1.44269504088896341f));
+                } else {
+                    v = kns_sigmoid(w->y[s][j]);
+                }
                 if (jit_on) v = jit(v, 1);
                 if (bf) v = sg < KNS_STAGES - 1 ? kns_round_bf16(v) : kns_round_fp16(v); /* GEMM operand / the mask's fp16 hand-off */
                 w->y[s][j] = v;

@@ -326,3 +326,58 @@ def test_front_end_context_extension(random_model, tmp_path):
     lib.pv_free_error_stack(ref)
     with pytest.raises(IOError):
         oracle.Oracle(p7)
+
+
+def _numpy_kns_v1(model_path, pcm):
+    """KNS-v1 restated a SECOND time, independently of oracle/kns_oracle.c: float64 numpy straight from the spec's
+    formulas and the parameter container -- numpy's rfft / irfft, exp, tanh, matrix products in whatever order BLAS likes.  Returns
+    (pcm_out int16, masks float64 [T, 257]).  Shares no code with the C oracle; agrees with it to float32 rounding."""
+    from koala_amd import params
+    p = {k: v.astype(np.float64) for k, v in params.read_params(model_path).items()}
+    n = len(pcm) // 256
+    win = np.sin(np.pi * np.arange(512) / 512)
+    hist, tail = np.zeros(256), np.zeros(256)
+    h = np.zeros((8, 271))
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))  # noqa: E731
+    out, masks = np.zeros(n * 256, np.int16), []
+
+    def gru(x, hp, w_ih, b_ih, w_hh, b_hh):
+        gi, gh = x @ w_ih + b_ih, hp @ w_hh + b_hh
+        r = sig(gi[:271] + gh[:271])
+        z = sig(gi[271:542] + gh[271:542])
+        c = np.tanh(gi[542:] + r * gh[542:])
+        return z * (hp - c) + c
+    for t in range(n):
+        fr = pcm[t * 256:(t + 1) * 256].astype(np.float64) / 32768.0
+        X = np.fft.rfft(np.concatenate([hist, fr]) * win)
+        hist = fr
+        f = (np.log(np.abs(X) ** 2 + 1e-10) - p['mean']) * p['scale']
+        e = f @ p['w_in'] + p['b_in']
+        y = np.zeros(0)
+        for s in range(4):
+            h[2 * s] = gru(np.concatenate([y, e]), h[2 * s], p['s%d.w_ih_a' % s], p['s%d.b_ih_a' % s], p['s%d.w_hh_a' % s], p['s%d.b_hh_a' % s])
+            h[2 * s + 1] = gru(h[2 * s], h[2 * s + 1], p['s%d.w_ih_b' % s], p['s%d.b_ih_b' % s], p['s%d.w_hh_b' % s], p['s%d.b_hh_b' % s])
+            y = sig(h[2 * s + 1] @ p['s%d.w_head' % s] + p['s%d.b_head' % s])
+        masks.append(y)
+        blk = np.fft.irfft(y * X, 512) * win
+        o = (tail + blk[:256]) * 32768.0
+        tail = blk[256:]
+        out[t * 256:(t + 1) * 256] = np.clip(np.sign(o) * np.floor(np.abs(o) + 0.5), -32768, 32767).astype(np.int16)
+    return out, np.array(masks)
+
+
+@pytest.mark.parametrize('kind', ['random', 'adaptive'])
+def test_oracle_agrees_with_an_independent_numpy_restatement(kind, test_pcm, noise_pcm):
+    """The oracle cannot be pinned to the reference's samples (licence-gated), so it is at least pinned to the SPEC twice: a float64
+    numpy restatement written from DESIGN.md section 2 alone must give the fp32 oracle's masks to float32 rounding and its PCM to the
+    last bit but for round-off ties."""
+    from conftest import model_file
+    model = model_file(kind)
+    a = 30 * 256
+    pcm = (test_pcm[a:a + 60 * 256].astype(int) + noise_pcm[a:a + 60 * 256]).astype(np.int16)
+    want, wmask = _numpy_kns_v1(model, pcm)
+    o = oracle.Oracle(model, 1)
+    got, gmask = o.process_with_mask(pcm[None, :])
+    assert np.abs(gmask[:, 0, :] - wmask).max() < 2e-4, float(np.abs(gmask[:, 0, :] - wmask).max())
+    d = np.abs(got[0].astype(int) - want.astype(int))
+    assert d.max() <= 1 and (d == 0).mean() > 0.99, (int(d.max()), float((d == 0).mean()))

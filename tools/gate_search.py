@@ -21,7 +21,7 @@ from oracle import oracle  # noqa: E402
 
 RANGES = {  # name: (lo, hi, log-scale?)
     'g': (3.0, 24.0, True), 's': (6.0, 55.0, True), 'g2': (0.8, 3.0, True), 'g3': (2.5, 9.0, True), 'b3': (-2.0, 0.0, False),
-    'thr': (0.05, 0.45, False), 'z_d': (0.05, 0.8, False), 'z_b': (0.3, 0.9, False), 'zb_rel': (1.0, 5.0, False), 'bz': (1.0, 4.0, False),
+    'thr': (-0.1, 0.45, False), 'z_d': (float(os.environ.get('GATE_ZD_MIN', '0.05')), 0.8, False), 'z_b': (0.3, 0.9, False), 'zb_rel': (1.0, 5.0, False), 'bz': (1.0, 4.0, False),
     'kappa': (0.8, 1.1, False), 'spread': (0.0, 0.8, False), 'thr_lf': (0.0, 0.6, False), 'hang': (0.0, 0.5, False), 'c0': (0.6, 1.0, False),
     'mask_spread': (0, 6, False),
 }
@@ -92,8 +92,10 @@ def evaluate(kw):
         params.write_params(path, params.make_adaptive_gate(**kw))
         env = envelope(path, _ctx['t'], _ctx['z'])
         res = {'env': env}
+        res['gain'] = kw.get('g', DEFAULTS['g']) * kw.get('g2', DEFAULTS['g2']) * kw.get('g3', DEFAULTS['g3']) / 4.0
         if env < 0.03:  # worth the rest
-            res['sens'], res['big'] = sensitivity(path, _ctx['x'])
+            if not os.environ.get('GATE_GAIN_CAP'):
+                res['sens'], res['big'] = sensitivity(path, _ctx['x'])
             if env < 0.02:
                 res['hold'] = holdout(path, _ctx['t'])
     finally:
@@ -103,6 +105,17 @@ def evaluate(kw):
 
 def cost(res):
     c = max(0.0, res['env'] - 0.0185) * 4000.0  # the envelope is the hard constraint
+    cap = os.environ.get('GATE_GAIN_CAP')
+    if cap:
+        # GATE_GAIN_CAP: bound the gain of the chain level -> detector -> layer B -> mask (g x g2 x g3 / 4 per unit of x) instead of
+        # scoring the sensitivity: what one flipped bf16 rounding (~0.002 in x) can do to a bin's mask is that gain times the flip
+        c += 30.0 * max(0.0, res['gain'] - float(cap)) + res['env'] * 100.0
+        h = res.get('hold')
+        if h:
+            c += 10 * max(0.0, 16.0 - h['steady_db']) + 10 * max(0.0, 9.0 - h['first_frames_db']) + 200 * max(0.0, 0.87 - h['speech_ratio'])
+        else:
+            c += 50.0
+        return c
     if 'sens' not in res:
         return c + 1000.0
     c += res['sens'] + 0.01 * res['big']

@@ -43,6 +43,10 @@ def main():
                 lib.pv_koala_process(k._handle, f.ctypes.data_as(C.POINTER(C.c_short)), out)
                 lat.append(time.perf_counter() - t0)
         lat = np.array(lat) * 1e6
+        if os.environ.get('LATENCY_DETAIL'):  # where the slow frames are: percentiles, and their positions within a pass over the file
+            slow = np.nonzero(lat > 1.1 * np.percentile(lat, 50))[0]
+            print(prec, 'percentiles 50/90/95/99/99.9: %s' % ' '.join('%.1f' % np.percentile(lat, q) for q in (50, 90, 95, 99, 99.9)),
+                  '| %d of %d frames above 1.1 x p50; positions mod %d: %s' % (len(slow), len(lat), n, sorted(set((slow % n).tolist()))[:40]))
         # the reference's perf loop (binding/python/test_koala_perf.py:42-58): all frames of test.wav through process()
         t0 = time.perf_counter()
         for f in frames:

@@ -23,10 +23,13 @@ def main():
     cases = [('random', 'bf16', 4096, 8, 60), ('random', 'fp32', 1000, 8, 40), ('random', 'bf16', 300, 16, 80), ('random5', 'bf16', 1030, 6, 60),
              ('random5', 'fp32', 77, 9, 60), ('adaptive', 'bf16', 2048, 4, 40), ('adaptive', 'fp32', 256, 32, 12), ('random', 'bf16', 17, 5, 200),
              ('random', 'fp32', 16, 3, 200), ('random', 'fp32', 200, 12, 60), ('random5', 'bf16', 100, 9, 60), ('random', 'bf16', 500, 40, 30)]
+    only = os.environ.get('SOAK_ONLY')  # e.g. adaptive:bf16
+    if only:
+        cases = [c for c in cases if '%s:%s' % (c[0], c[1]) == only]
     bad = 0
     for kind, precision, B, Tmax, calls in cases:
         calls = max(4, int(calls * scale))
-        model = model_file(kind)
+        model = os.environ.get('SOAK_MODEL') or model_file(kind)  # (SOAK_MODEL: a candidate parameter file in place of the case's)
         kb = koala_amd.create_batch('key', B, Tmax, precision, model_path=model)
         ref = oracle.Oracle(model, B, oracle.PREC_BF16 if precision == 'bf16' else oracle.PREC_FP32)
         worst, within1, n = 0, 0, 0
