@@ -229,11 +229,11 @@ __all__ = ["write_params", "read_params", "make_random", "make_gate", "make_adap
            "tensor_order"]
 
 
-def make_adaptive_gate(mu: float = -9.0, sigma: float = 0.125, a: float = 0.5, c0: float = 0.9, s: float = 51.25,
-                       bz: float = 2.75, kappa: float = 1.0, g: float = 22.275, thr: float = 0.24, z_d: float = 0.1,
-                       g2: float = 1.521, z_b: float = 0.64, g3: float = 8.25, b3: float = -0.85,
-                       spread: float = 0.416, thr_lf: float = 0.405, lf_bands: float = 1.6, zb_rel: float = 3.6,
-                       ctx: float = 0.0, ctx_width: int = 8, hang: float = 0.3, hang_lo: int = 8, hang_hi: int = 100,
+def make_adaptive_gate(mu: float = -9.0, sigma: float = 0.125, a: float = 0.5, c0: float = 0.8479, s: float = 55.0,
+                       bz: float = 1.2482, kappa: float = 0.9398, g: float = 7.3185, thr: float = 0.2119, z_d: float = 0.0555,
+                       g2: float = 0.9973, z_b: float = 0.6758, g3: float = 4.358, b3: float = -0.5427,
+                       spread: float = 0.4168, thr_lf: float = 0.4055, lf_bands: float = 1.6, zb_rel: float = 4.1415,
+                       ctx: float = 0.0, ctx_width: int = 8, hang: float = 0.2868, hang_lo: int = 8, hang_hi: int = 100,
                        hang_gain: float = 4.374, hang_ref: float = 0.81, hang_z0: float = 6.8, hang_z1: float = 9.0,
                        hang_bands: int = 4, mask_spread: int = 0) -> Dict[str, np.ndarray]:
     """
@@ -244,6 +244,14 @@ def make_adaptive_gate(mu: float = -9.0, sigma: float = 0.125, a: float = 0.5, c
     those three cases, and tests/test_holdout.py therefore checks the set on noises that took no part in it.
     No training data exists in this environment: the set shows that the KNS-v1 topology can express a working suppressor
     for stationary noise; it is a spectral gate, it does not separate speech from speech-like noise.
+
+    Round 5 ("adaptive-gate-v3"): the constants were searched again with the GAIN of the chain band level -> detector -> layer B ->
+    mask, g x g2 x g3 / 4 per unit of x, capped at 8 (tools/gate_search.py, GATE_GAIN_CAP).  Rounds 2-4 shipped a hard gate (g = 22.3,
+    g3 = 8.25: gain ~70, the mask switches within 1-2 dB of band level); in the bf16 configuration one flipped rounding of an operand
+    (a 0.1-0.3 dB step of a band level or of the tracked floor) then moved a bin's mask by up to ~9 % -- 29-35 LSB outliers against the
+    oracle in a long soak.  At gain 8 the mask follows the level over ~15-20 dB like a Wiener gain, the same soak stays within the
+    suite's bars (tests/test_gpu_parity.py::test_bf16_default_model_soak), and tests/test_holdout.py bounds the model's sensitivity
+    on the CPU (kns_oracle_set_jitter).  The price is depth: stationary hold-out noise is suppressed by 16-21 dB instead of 21-33.
 
       features  f_k = (ln P_k - mu) sigma with generic constants (ln P in [-23, 5] -> f in [-1.75, 1.75]).
       front-end e_j, j < 128: mean of f over band j (bins 2j, 2j+1; band 127 also takes bin 256), plus `spread` of each
