@@ -17,11 +17,13 @@ Prints ONE JSON line (rank 0).  Besides the driver's fields it carries
                 duration measured with HIP events on the engine's stream in a second, identical pass
   stages        the same for every kernel class (HBM-bound stages also against the bytes they were measured to move)
   cpu_baseline  the CPU oracle (a "port": plain-C restatement, OpenMP over stream blocks) on a bounded sample of the
-                same workload on this box's host cores -- a reported baseline, not the target
+                same workload on this box's host cores, in a child process bound one thread per physical core
+                (`cores` = threads used; `noisy` when the box never went quiet) -- a reported baseline, not the target
   extra         the other BASELINE operating points, timed in the same run (N = 1 only): configs[1] (256 streams,
                 fp32), configs[4] (one stream, one frame per pv_koala_process call: p50/p99), one frame per call at
-                4096 streams, the host-pointer (PCIe-inclusive) path, and the |GPU - oracle| histogram of the timed
-                batch's first call
+                4096 streams, the host-pointer (PCIe-inclusive) paths -- synchronous calls on pageable and page-locked
+                buffers, asynchronous calls rotating over three page-locked buffer pairs -- and the |GPU - oracle|
+                histogram of the timed batch's first call
 """
 import argparse
 import json

@@ -6,11 +6,11 @@ it is NOT expected to handle: speech-like babble (amplitude-modulated formant re
 checked against the same oracle sample for sample elsewhere.
 
 Bars (levels 0.01 and 0.03 RMS, i.e. around and above the reference's noise fixture at 0.023): stationary noise alone is
-suppressed by >= 15 dB after 0.5 s (measured 21-33 dB) and by >= 8 dB in the first four frames, while the floor tracker is
-still coming down from its closed start (measured 12.6-13.4 dB; the reference's own test checks those frames against an
-absolute 0.02 RMS, test_koala.py:94-95); with speech on top, speech-active frames keep >= 85 % (median) of the clean
-speech's RMS (measured 0.95-1.02).  At 0.06 RMS the suppression of pink and rumble noise drops to 10-11 dB.  Babble: what is
-measured is recorded, the bar is only "does no harm".
+suppressed by >= 15 dB after 0.5 s (measured 16.7-23.5 dB with round 5's constants; round 4's hard gate: 21-33 dB, at the price of a
+bf16 path that amplified single rounding flips -- DESIGN.md section 2.4) and by >= 8 dB in the first four frames, while the floor
+tracker is still coming down from its closed start (measured 9.2-9.8 dB; the reference's own test checks those frames against an
+absolute 0.02 RMS, test_koala.py:94-95); with speech on top, speech-active frames keep >= 85 % (median) of the clean speech's RMS
+(measured 0.86-0.95).  Babble: what is measured is recorded (7 dB), the bar is only "does no harm".
 """
 import numpy as np
 import pytest
