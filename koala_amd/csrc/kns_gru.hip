@@ -910,159 +910,10 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     if (q16) g.hstate_out[(((size_t) mt * kUnitTiles + u2) * 64 + lane) * 4 + e16] = h16;
 }
 
-#ifdef KNS_R8X2
-// ---- TIMING EXPERIMENT (round 5; results are garbage: unit tile 16 and the narrow heads are left out).
-// The question behind the producer/consumer decomposition: what does a step cost when ONE workgroup keeps W_hh resident and runs
-// TWO m-tiles (32 streams) through it, so that a wave always has the MFMAs of one m-tile to issue while the gate arithmetic of the
-// other is in flight?  Same residency as gru_resident8_kernel (42 fragments per wave in registers, 12 in LDS); a second hidden-state
-// image and a second set of state / pre-activation registers take the place of tile 16's weights and hand-over.
-// KNS_R8X2 bit 0: waves 4..7 (the second wave of every SIMD) take the m-tiles in the opposite order; bit 1: waves 0..3 raise their
-// priority inside their MFMA loops (breaks the symmetric contention that keeps two waves of a SIMD in phase).
-__global__ __launch_bounds__(64 * kR8Waves, 2) void gru_r8x2_kernel(GruArgs g) {
-    typedef PBF16 P;
-    typedef P::frag_t frag_t;
-    constexpr int NBH = P::NBH;
-    constexpr int kLdsW = kR8Waves * (kR8LdsFrags0 + kR8LdsFrags1) * 1024;
-    __shared__ __attribute__((aligned(16))) char smem[4 * NBH * 1024 + kLdsW];
-    frag_t *wl1 = (frag_t *) (smem + 4 * NBH * 1024);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int colq = lane & 15, rowq = (lane >> 4) * 4;
-    const frag_t *whh = (const frag_t *) g.whh;
-    const int u0 = wave, u1 = wave + 8;
-    typedef const __attribute__((address_space(1))) void *gptr_t;
-    typedef __attribute__((address_space(3))) void *lptr_t;
-    frag_t *wl0w = wl1 + wave * (kR8LdsFrags0 + kR8LdsFrags1) * 64, *wl1w = wl0w + kR8LdsFrags0 * 64;
-#pragma unroll
-    for (int i = kR8RegFrags0; i < 27; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t) (whh + ((size_t) (u0 * 3 + i % 3) * NBH + i / 3) * 64 + lane),
-                                         (lptr_t) (wl0w + (i - kR8RegFrags0) * 64), 16, 0, 0);
-#pragma unroll
-    for (int i = kR8RegFrags1; i < 27; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t) (whh + ((size_t) (u1 * 3 + i % 3) * NBH + i / 3) * 64 + lane),
-                                         (lptr_t) (wl1w + (i - kR8RegFrags1) * 64), 16, 0, 0);
-    frag_t w0[kR8RegFrags0], w1[kR8RegFrags1];
-#pragma unroll
-    for (int i = 0; i < kR8RegFrags0; ++i) w0[i] = whh[((size_t) (u0 * 3 + i % 3) * NBH + i / 3) * 64 + lane];
-#pragma unroll
-    for (int i = 0; i < kR8RegFrags1; ++i) w1[i] = whh[((size_t) (u1 * 3 + i % 3) * NBH + i / 3) * 64 + lane];
-    // (bit 0) the second wave of every SIMD sees the two m-tiles in the opposite order: logical m-tile m of a wave is physical m ^ sw --
-    // addresses follow the physical index, register arrays the logical one (no second copy of the step's code)
-    const int sw = __builtin_amdgcn_readfirstlane(((KNS_R8X2 & 1) && wave >= 4) ? 1 : 0);
-    f32x4 hreg[2][2];
-    P::gi_t gi[2][2][3];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int mt = 2 * blockIdx.x + (m ^ sw);
-        hreg[m][0] = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u0) * 64 + lane];
-        hreg[m][1] = ((const f32x4 *) g.hstate_in)[((size_t) mt * kUnitTiles + u1) * 64 + lane];
-        const P::gi_t *gp = (const P::gi_t *) g.gi + (size_t) mt * kGateTiles * 64;
-#pragma unroll
-        for (int gt = 0; gt < 3; ++gt) {
-            gi[m][0][gt] = gp[(u0 * 3 + gt) * 64 + lane];
-            gi[m][1][gt] = gp[(u1 * 3 + gt) * 64 + lane];
-        }
-    }
-    for (int i = tid; i < 4 * NBH * 64; i += 64 * kR8Waves) ((uint4 *) smem)[i] = uint4{0, 0, 0, 0};
-    __syncthreads();
-    if (tid < 128) {  // the constant 1 at k = 271, 272 of all four images
-        const int k = kBiasK0 + ((tid >> 4) & 1);
-        ((uint16_t *) (smem + (tid >> 5) * NBH * 1024))[(k / P::KB) * 64 * P::EPL + P::off(tid & 15, k % P::KB)] = (uint16_t) kBf16One;
-    }
-    auto put_h = [&](char *buf, int u, const f32x4 &h) {
-        const int k = u * 16 + colq;
-        uint16_t *dst = (uint16_t *) buf + (k / P::KB) * 64 * P::EPL + P::off(rowq, k % P::KB);
-        const uint32_t lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{h[0], h[1]}, bf16x2));
-        const uint32_t hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{h[2], h[3]}, bf16x2));
-        dst[0] = (uint16_t) lo;
-        dst[8] = (uint16_t) (lo >> 16);
-        dst[16] = (uint16_t) hi;
-        dst[24] = (uint16_t) (hi >> 16);
-    };
-    // images: [m-tile][ping-pong]
-    auto image = [&](int m, int pp) { return smem + ((m ^ sw) * 2 + pp) * NBH * 1024; };
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        put_h(image(m, 0), u0, hreg[m][0]);
-        put_h(image(m, 0), u1, hreg[m][1]);
-    }
-    __syncthreads();
-    const unsigned lane8 = lane * 8u;
-    const size_t hs_stride = (size_t) g.mtiles * NBH * 1024, gi_stride = (size_t) g.mtiles * kGateTiles * 512;
-    const char *hs_base = (const char *) g.hseq + (size_t) (2 * blockIdx.x) * NBH * 1024;
-    const char *gn_base = (const char *) g.gi + (size_t) (2 * blockIdx.x) * kGateTiles * 512 + (g.T > 1 ? gi_stride : 0);
-    auto publish = [&](const frag_t *src, const char *slot_base) {
-        const __amdgpu_buffer_rsrc_t hs = make_rsrc(slot_base, NBH * 1024);
-        const unsigned i0 = wave * 64 + lane, i1 = 8 * 64 + wave * 8 + (lane & 7);
-        const frag_t x0 = src[i0];
-        buf_store_frag(hs, i0 * 16u, x0);
-        const frag_t x1 = src[i1];
-        buf_store_frag(hs, lane < 8 ? i1 * 16u : 0x7fffff00u, x1);
-    };
-    for (int t = 0; t < g.T; ++t) {
-        KNS_STAMP(0);
-        KNS_STAMP_AT(9, 8);
-        KNS_STAMP_AT(10, 24);
-        const int pp = t & 1;
-        publish((const frag_t *) (smem + pp * NBH * 1024), hs_base);
-        publish((const frag_t *) (smem + (2 + pp) * NBH * 1024), hs_base + NBH * 1024);
-        const __amdgpu_buffer_rsrc_t gnext = make_rsrc(gn_base, 2 * kGateTiles * 512);
-        hs_base += t > 0 ? hs_stride : 0;
-        gn_base += t + 2 < g.T ? gi_stride : 0;
-        auto gates = [&](const int m, const int q, f32x4 (&acc)[3]) {
-            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            const u32x2 vr = __builtin_bit_cast(u32x2, gi[m][q][0]), vz = __builtin_bit_cast(u32x2, gi[m][q][1]),
-                        vn = __builtin_bit_cast(u32x2, gi[m][q][2]);
-            const unsigned pr[2] = {vr[0], vr[1]}, pz[2] = {vz[0], vz[1]}, pn[2] = {vn[0], vn[1]};
-            const int u = q ? u1 : u0;
-#pragma unroll
-            for (int gt = 0; gt < 3; ++gt) gi[m][q][gt] = buf_load_gi(gnext, lane8, ((m ^ sw) * kGateTiles + u * 3 + gt) * 512u);
-            const f32x4 hnew = gate_block_bf16(pr, pz, pn, acc[0], acc[1], acc[2], hreg[m][q]);
-            hreg[m][q] = hnew;
-            put_h(image(m, pp ^ 1), u, hnew);
-        };
-        auto tile_pair = [&](const int m, const int stamp0) {
-            const frag_t *ha = (const frag_t *) image(m, pp);
-            f32x4 acc[3];
-#pragma unroll
-            for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if ((KNS_R8X2 & 2) && wave < 4) __builtin_amdgcn_s_setprio(2);
-            r8_tile_mma<kR8RegFrags0, R8C_Q, kR8RegFrags0>(acc, ha, w0, wl0w, lane);
-            if ((KNS_R8X2 & 2) && wave < 4) __builtin_amdgcn_s_setprio(0);
-            KNS_STAMP(stamp0);
-            gates(m, 0, acc);
-            KNS_STAMP(stamp0 + 1);
-#pragma unroll
-            for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if ((KNS_R8X2 & 2) && wave < 4) __builtin_amdgcn_s_setprio(2);
-            r8_tile_mma<kR8RegFrags1, 3, kR8RegFrags1>(acc, ha, w1, wl1w, lane);
-            if ((KNS_R8X2 & 2) && wave < 4) __builtin_amdgcn_s_setprio(0);
-            KNS_STAMP(stamp0 + 2);
-            gates(m, 1, acc);
-            KNS_STAMP(stamp0 + 3);
-        };
-        tile_pair(0, 1);
-        tile_pair(1, 5);
-        __syncthreads();
-        KNS_STAMP(11);
-    }
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int mt = 2 * blockIdx.x + (m ^ sw);
-        publish((const frag_t *) image(m, g.T & 1), (const char *) g.hseq + ((size_t) (g.T - 1) * g.mtiles + mt) * NBH * 1024);
-        ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u0) * 64 + lane] = hreg[m][0];
-        ((f32x4 *) g.hstate_out)[((size_t) mt * kUnitTiles + u1) * 64 + lane] = hreg[m][1];
-    }
-}
-#endif
-
+// (Round 5 measured a form of the resident kernel that runs TWO m-tiles per workgroup -- the consumer half of a producer/consumer CU
+// pair -- as a timing variant, gru_r8x2_kernel: 4 113-4 492 ticks per m-tile-step against 4 714, on half the chip; not adopted.  The
+// source left the tree with the experiment: last commit that holds it is a6273b0; record: profiles/r05_r8x2_consumer.txt.)
 void launch_gru(const GruArgs &a, hipStream_t s) {
-#ifdef KNS_R8X2
-    if (a.precision == kBf16 && a.mtiles % 2 == 0) {
-        hipLaunchKernelGGL(gru_r8x2_kernel, dim3(a.mtiles / 2), dim3(64 * kR8Waves), 0, s, a);
-        return;
-    }
-#endif
     const bool stream_weights = (a.dev & kDevGruStream) != 0;  // A/B switch (developer build only)
     if (a.precision == kBf16 && !stream_weights && a.yw)
         hipLaunchKernelGGL(gru_resident8_kernel<true>, dim3(a.mtiles), dim3(64 * kR8Waves), 0, s, a);
