@@ -97,6 +97,23 @@ __device__ __forceinline__ float kns_log(float x) {
     return __builtin_fmaf(fe, 0.693359375f, r);
 }
 
+// ln x of the bf16 configuration's FEATURES (round 5): x = m 2^e with m in [0.5, 1) (frexp), ln x = e ln 2 + p(m), p a degree-4
+// polynomial (max error 7e-5: a feature moves by 9e-6, its bf16 rounding step is ~2e-3).  Built from IEEE operations only and written
+// twice (oracle/kns_oracle.c, kns_log_fast), so the bf16 features are the SAME BITS on both sides -- with the hardware v_log_f32 a
+// feature's rounding flipped now and then, and the default model turned such a flip (a 0.1-0.3 dB step of a band level) into its
+// largest PCM differences (tools/model_sensitivity.py).  Eight full-rate instructions per bin against a quarter-rate v_log_f32 and a
+// multiplication: +3 cycles per bin and lane group.
+__device__ __forceinline__ float kns_log_fast(float x) {
+    const float m = __builtin_amdgcn_frexp_mantf(x);
+    const float e = (float) __builtin_amdgcn_frexp_expf(x);
+    float p = -8.873490199e-01f;
+    p = __builtin_fmaf(p, m, 3.524021909e+00f);
+    p = __builtin_fmaf(p, m, -5.820779088e+00f);
+    p = __builtin_fmaf(p, m, 5.613961063e+00f);
+    p = __builtin_fmaf(p, m, -2.429906919e+00f);
+    return __builtin_fmaf(e, 0.693147180559945309f, p);
+}
+
 __device__ __forceinline__ float kns_sigmoid(float x) { return 1.0f / (1.0f + kns_exp(-x)); }
 
 __device__ __forceinline__ float kns_tanh(float x) {

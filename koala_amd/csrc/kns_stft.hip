@@ -94,9 +94,10 @@ __device__ __forceinline__ void real_spectrum(const cpx (&z)[16], cpx (&x)[16], 
 
 template <class P>
 __device__ __forceinline__ float feature_log(float x) {
-    // fp32 configuration: the spec's polynomial (bit-comparable with the oracle).  bf16 configuration: the feature is
-    // rounded to bf16 (8 bits) right after, so the hardware logarithm (1 ulp) is what the tolerance-specified mode uses.
-    if (P::kPrec == kBf16) return __builtin_amdgcn_logf(x) * 0.693147180559945309f;
+    // fp32 configuration: the spec's full-precision polynomial.  bf16 configuration: the feature is rounded to bf16 (8 bits) right
+    // after, so a short polynomial serves -- an exactly reproducible one (kns_log_fast), not the hardware logarithm: the features of
+    // the two configurations are each bit-identical to the oracle's.
+    if (P::kPrec == kBf16) return kns_log_fast(x);
     return kns_log(x);
 }
 

@@ -118,20 +118,34 @@ float kns_tanh(float x) {
     return copysignf(v, x);
 }
 
-/* ---- bf16 mode (round 5): the transcendentals of the tolerance-specified configuration are the CORRECTLY ROUNDED functions 2^x and
- * log2 x (via double precision; 1 / x already is IEEE division), evaluated in the engine's operation order -- gates: 1 / (1 + 2^y) on the
+/* ---- bf16 mode (round 5): the gate / head transcendentals of the tolerance-specified configuration are the CORRECTLY ROUNDED 2^x
+ * (via double precision; 1 / x already is IEEE division), evaluated in the engine's operation order -- gates: 1 / (1 + 2^y) on the
  * pre-scaled pre-activations; heads: 1 / (1 + 2^(x * -log2 e)); features: log2(P) * ln 2.  The hardware's v_exp_f32 / v_log_f32 /
  * v_rcp_f32 are within one ulp of those, so the two sides now differ only where the hardware is not correctly rounded; rounds 1-4
  * used the fp32 mode's polynomials here (1-2 ulp off in their own direction, and e^(y ln 2) carries |y| ulps of the product's
  * rounding), which doubled the distance for no reason.  The fp32 mode keeps the polynomials: it is bit-comparable with the GPU. */
 static inline float kns_exp2_cr(float y) { return (float) exp2((double) y); }
-static inline float kns_log2_cr(float x) { return (float) log2((double) x); }
+/* ... except the FEATURES' logarithm, which is a short polynomial evaluated identically on both sides (kns_device.hpp, kns_log_fast):
+ * x = m 2^e, m in [0.5, 1); ln x = e ln 2 + p(m), degree 4, max error 7e-5 (the feature is rounded to bf16 right after).  The bf16
+ * features are therefore the engine's bits, like the fp32 ones. */
+float kns_log_fast(float x) {
+    int ei;
+    const float m = frexpf(x, &ei);
+    const float e = (float) ei;
+    float p = -8.873490199e-01f;
+    p = fmaf(p, m, 3.524021909e+00f);
+    p = fmaf(p, m, -5.820779088e+00f);
+    p = fmaf(p, m, 5.613961063e+00f);
+    p = fmaf(p, m, -2.429906919e+00f);
+    return fmaf(e, 0.693147180559945309f, p);
+}
 
 /* ---- sensitivity probe (KNS_ORACLE_JITTER=<seed>, bf16 mode only; tools/model_sensitivity.py).  The bf16 configuration is
  * specified to a tolerance: a second valid implementation (the GPU: hardware 2^x / 1/x / log2, an MFMA that sums eight products
  * before it rounds -- profiles/r05_mfma_probe.txt) differs from this restatement in the last bit of a transcendental or a GEMM
  * output now and then, and such a difference occasionally flips a bf16 / fp16 rounding downstream.  With the knob set, the
- * oracle plays that second implementation: the last bit of every transcendental result moves by +-1 ulp with probability 1/2
+ * oracle plays that second implementation: the last bit of every gate / head transcendental result moves by +-1 ulp with probability 1/2
+ * (the features do not take part: their logarithm is the same polynomial on every side)
  * and of every GEMM output with probability 1/8, from a generator seeded by (seed, stream, frame) -- so the PCM distance between a
  * plain and a jittered run of ONE model on the CPU predicts what the GPU-vs-oracle comparison of that model will show, which is how
  * the default model's sensitivity is judged without a GPU (tests/test_holdout.py).  Never set in a parity test. */
@@ -494,10 +508,9 @@ static void spectrum512(const kns_params_t *p, const int16_t *hist, const int16_
     spec[2 * 256 + 1] = 0.0f;
 }
 
-/* ln of the power + 1e-10: the spec's polynomial in the fp32 mode; in the bf16 mode the engine's log2(x) * ln 2 with the correctly
- * rounded log2 (kns_log2_cr above) */
+/* ln of the power + 1e-10: the spec's full-precision polynomial in the fp32 mode, the short one in the bf16 mode (kns_log_fast) */
 static inline float feature_log(const kns_params_t *p, float x) {
-    return p->precision == KNS_PREC_BF16 ? kns_log2_cr(x) * 0.693147180559945309f : kns_log(x);
+    return p->precision == KNS_PREC_BF16 ? kns_log_fast(x) : kns_log(x);
 }
 
 static void analysis(const kns_params_t *p, const int16_t *hist, const int16_t *pcm, float *spec, float *feat) {
@@ -947,8 +960,6 @@ static void frame_block(const kns_params_t *p, int nb, kns_stream_t **st, const 
         analysis(p, st[s]->hist, pcm[s], w->spec[s], w->feat[s]);
         memcpy(st[s]->hist, pcm[s], sizeof(int16_t) * KNS_FRAME);
         st[s]->frames++;
-        if (jit_on) /* the logarithm's last bit, carried through (x - mean) * scale: one ulp of the feature at most */
-            for (int k = 0; k < KNS_BINS; ++k) w->feat[s][k] = jit(w->feat[s][k], 1);
     }
     if (p->fold) {
         memset(w->e, 0, sizeof(float) * (size_t) nb * KNS_H); /* no embedding: the stages read the features (fold_front) */

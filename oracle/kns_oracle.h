@@ -99,6 +99,7 @@ void kns_oracle_synthesis_radix2(const float *spectrum, const float *mask, float
 /* scalar math of the spec (exposed so tests can compare the GPU's device functions bit for bit) */
 float kns_exp(float x);
 float kns_log(float x);
+float kns_log_fast(float x); /* the bf16 mode's feature logarithm */
 float kns_sigmoid(float x);
 float kns_tanh(float x);
 float kns_round_bf16(float x);

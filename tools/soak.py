@@ -67,7 +67,7 @@ def main():
             worst = max(worst, int(d.max()))
             within1 += int((d <= 1).sum())
             n += d.size
-        tol = (8 if kind == 'adaptive' else 5) if precision == 'bf16' else 0  # (the default model's bar: tests/test_gpu_parity.py, BF16_DEFAULT_MODEL_TOL)
+        tol = 5 if precision == 'bf16' else 0
         ok = worst <= tol and (precision != 'bf16' or within1 / n >= 0.999)
         bad += not ok
         print('%-8s %s B=%-5d Tmax=%-3d %4d calls: worst |gpu - oracle| = %d LSB, %.4f %% within 1 LSB  %s'
