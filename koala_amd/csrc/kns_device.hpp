@@ -431,33 +431,6 @@ __device__ __forceinline__ f32x4 gate_block_bf16(const unsigned (&pr)[2], const 
     }
     return hnew;
 }
-#ifdef KNS_GATE_LUT
-// TIMING EXPERIMENT (round 5): the gate nonlinearities as a table lookup in LDS + linear interpolation instead of v_exp_f32 + v_rcp_f32
-// (six quarter-rate instructions per hidden unit are 1 536 of the ~2 600 VALU cycles a SIMD spends per m-tile-step).  tab: 256 entries
-// {S(t_i), S(t_{i+1}) - S(t_i)}, t_i = (i - 128) / 8 in the pre-scaled (log2) domain; one ds_read_b64 per evaluation.
-__device__ __forceinline__ float lut_eval(const char *tab, float t) {
-    float u = __builtin_fmaf(t, 8.0f, 128.0f);
-    u = __builtin_amdgcn_fmed3f(u, 0.0f, 255.996f);
-    const unsigned i = (unsigned) u;
-    const float f = __builtin_amdgcn_fractf(u);
-    const float2 vd = *(const float2 *) (tab + i * 8u);
-    return __builtin_fmaf(f, vd.y, vd.x);
-}
-__device__ __forceinline__ f32x4 gate_block_lut(const char *tabS, const char *tabN, const unsigned (&pr)[2], const unsigned (&pz)[2],
-                                                const unsigned (&pn)[2], const f32x4 &ar, const f32x4 &az, const f32x4 &an, const f32x4 &hprev) {
-    const float one = opaque_one();
-    f32x4 hnew;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const float r0 = lut_eval(tabS, mix_add<0>(pr[p], ar[2 * p], one)), r1 = lut_eval(tabS, mix_add<1>(pr[p], ar[2 * p + 1], one));
-        const float z0 = lut_eval(tabS, mix_add<0>(pz[p], az[2 * p], one)), z1 = lut_eval(tabS, mix_add<1>(pz[p], az[2 * p + 1], one));
-        const float n0 = lut_eval(tabN, mix_fma<0>(r0, an[2 * p], pn[p])), n1 = lut_eval(tabN, mix_fma<1>(r1, an[2 * p + 1], pn[p]));
-        hnew[2 * p] = __builtin_fmaf(z0, hprev[2 * p] - n0, n0);
-        hnew[2 * p + 1] = __builtin_fmaf(z1, hprev[2 * p + 1] - n1, n1);
-    }
-    return hnew;
-}
-#endif
 // the same on one element with the pre-activations already converted to fp32 (exactly: fp16 -> fp32 is exact, and
 // fma(x, 1, t) = x + t)
 __device__ __forceinline__ float gate_elem_bf16(float xr, float xz, float xn, float ar, float az, float an, float hprev) {

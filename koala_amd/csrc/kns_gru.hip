@@ -682,18 +682,7 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     typedef PBF16 P;
     typedef P::frag_t frag_t;
     constexpr int NBH = P::NBH;
-#ifdef KNS_GATE_LUT
-    __shared__ __attribute__((aligned(16))) char smem[kR8Lds + 3 * 1024 + 16 + (kYHead ? kR8HeadLds : 0) + 4096 + 16];
-    const char *tabS = smem + ((kR8Lds + 3 * 1024 + 16 + (kYHead ? kR8HeadLds : 0) + 15) & ~15), *tabN = tabS + 2048;
-    if (threadIdx.x < 256) {
-        const float t0 = ((float) threadIdx.x - 128.0f) * 0.125f, t1 = t0 + 0.125f;
-        const float v0 = 1.0f / (1.0f + exp2f(t0)), v1 = 1.0f / (1.0f + exp2f(t1));
-        ((float2 *) tabS)[threadIdx.x] = float2{v0, v1 - v0};
-        ((float2 *) tabN)[threadIdx.x] = float2{1.0f - 2.0f * v0, -2.0f * (v1 - v0)};
-    }
-#else
     __shared__ __attribute__((aligned(16))) char smem[kR8Lds + 3 * 1024 + 16 + (kYHead ? kR8HeadLds : 0)];
-#endif
     frag_t *wlh = (frag_t *) (smem + kR8Lds + 3 * 1024 + 16);  // (kYHead) [9][64]: the head's n-tile 0
     char *hbuf0 = smem, *hbuf1 = smem + NBH * 1024;
     frag_t *wl1 = (frag_t *) (smem + 2 * NBH * 1024);                                   // [8 waves][13][64]: first tile's, then second tile's
@@ -851,11 +840,7 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
             const int u = q ? u1 : u0;
 #pragma unroll
             for (int gt = 0; gt < 3; ++gt) gi[q][gt] = buf_load_gi(gnext, lane8, (u * 3 + gt) * 512u);
-#ifdef KNS_GATE_LUT
-            const f32x4 hnew = gate_block_lut(tabS, tabN, pr, pz, pn, acc[0], acc[1], acc[2], hreg[q]);
-#else
             const f32x4 hnew = gate_block_bf16(pr, pz, pn, acc[0], acc[1], acc[2], hreg[q]);
-#endif
             hreg[q] = hnew;
             put_h(hn, u, hnew);
         };
@@ -904,15 +889,7 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
                 const float ar = ((const float *) acc16)[(0 * 64 + lane) * 4 + e16];
                 const float az = ((const float *) acc16)[(1 * 64 + lane) * 4 + e16];
                 const float an = ((const float *) acc16)[(2 * 64 + lane) * 4 + e16];
-#ifdef KNS_GATE_LUT
-                {
-                    const float r = lut_eval(tabS, xr + ar), z = lut_eval(tabS, xz + az);
-                    const float n = lut_eval(tabN, __builtin_fmaf(r, an, xn));
-                    h16 = __builtin_fmaf(z, h16 - n, n);
-                }
-#else
                 h16 = gate_elem_bf16(xr, xz, xn, ar, az, an, h16);
-#endif
                 put_h16(hn, h16);
             }
         }
@@ -935,7 +912,9 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
 
 // (Round 5 measured a form of the resident kernel that runs TWO m-tiles per workgroup -- the consumer half of a producer/consumer CU
 // pair -- as a timing variant, gru_r8x2_kernel: 4 113-4 492 ticks per m-tile-step against 4 714, on half the chip; not adopted.  The
-// source left the tree with the experiment: last commit that holds it is a6273b0; record: profiles/r05_r8x2_consumer.txt.)
+// source left the tree with the experiment: last commit that holds it is a6273b0; record: profiles/r05_r8x2_consumer.txt.  Likewise the
+// gates as LDS table lookups instead of v_exp_f32 / v_rcp_f32 (-DKNS_GATE_LUT: 158 -> 196 us per launch; last commit ba172d7,
+// profiles/r05_gate_lut.txt).)
 void launch_gru(const GruArgs &a, hipStream_t s) {
     const bool stream_weights = (a.dev & kDevGruStream) != 0;  // A/B switch (developer build only)
     if (a.precision == kBf16 && !stream_weights && a.yw)
