@@ -35,23 +35,29 @@ def load(pattern, root):
 def main(root):
     k = load('*kernel_trace.csv', root)
     m = load('*memory_copy_trace.csv', root)
-    kern = [(int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in k if 'kns::' in r.get('Kernel_Name', '')]
-    big = [r for r in m if int(r['End_Timestamp']) - int(r['Start_Timestamp']) > 500000]  # the calls' 134 MB copies (> 0.5 ms)
-    h2d = [(int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in big if 'HOST_TO_DEVICE' in r.get('Direction', '').upper()]
-    d2h = [(int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in big if 'DEVICE_TO_HOST' in r.get('Direction', '').upper()]
-    print('%d engine kernels, %d large host-to-device and %d large device-to-host copies' % (len(kern), len(h2d), len(d2h)))
+    iv = lambda r: (int(r['Start_Timestamp']), int(r['End_Timestamp']))  # noqa: E731
+    long_ = lambda r: int(r['End_Timestamp']) - int(r['Start_Timestamp']) > 500000  # noqa: E731  (the calls' 134 MB copies: > 0.5 ms)
+    kern = [iv(r) for r in k if 'kns::' in r.get('Kernel_Name', '')]
+    h2d = sorted(iv(r) for r in m if long_(r) and 'HOST_TO_DEVICE' in r['Direction'].upper())
+    # the asynchronous calls' copy-outs into page-locked host memory are done by the runtime's copy KERNEL (no SDMA record);
+    # the synchronous path's strided 2-D copies appear as DEVICE_TO_DEVICE records on the GPU agent
+    d2h = sorted([iv(r) for r in k if 'copyBuffer' in r.get('Kernel_Name', '') and long_(r)] +
+                 [iv(r) for r in m if long_(r) and 'HOST_TO_DEVICE' not in r['Direction'].upper()])
+    print('%d engine kernels, %d large host-to-device copies, %d large copy-outs' % (len(kern), len(h2d), len(d2h)))
     if not (kern and h2d and d2h):
         return
-    # the steady-state window of the LAST asynchronous run: from the 4th-last H2D's start to the 4th-last D2H's end would cut the drain;
-    # simpler and conservative: the span in which copies of both directions exist
-    lo = max(min(s for s, _ in h2d), min(s for s, _ in d2h))
-    hi = min(max(e for _, e in h2d), max(e for _, e in d2h))
-    clip = lambda iv: [(max(s, lo), min(e, hi)) for s, e in iv if e > lo and s < hi]  # noqa: E731
+    # steady state of the LAST asynchronous run of tools/host_async.py (30 calls, three buffer pairs): its copy-ins are the last 30
+    # whole-call host-to-device copies (> 2 ms each; the synchronous path that follows copies in sub-chunks of 16 frames)
+    whole = [c for c in h2d if c[1] - c[0] > 2000000][-30:]
+    lo, hi = whole[3][0], whole[-1][1]  # (skip the pipeline's fill)
+    clip = lambda x: [(max(s, lo), min(e, hi)) for s, e in x if e > lo and s < hi]  # noqa: E731
     span = hi - lo
-    for name, iv in (('kernels', kern), ('host-to-device', h2d), ('device-to-host', d2h)):
-        print('%-16s busy %7.2f ms of %7.2f ms = %5.1f %%' % (name, union(clip(iv)) / 1e6, span / 1e6, 100.0 * union(clip(iv)) / span))
-    both = union(clip(h2d)) + union(clip(d2h)) + union(clip(kern))
-    print('sum of the three busy times = %.2f x the window: that much runs concurrently' % (both / span))
+    total = 0
+    for name, x in (('engine kernels', kern), ('host-to-device', h2d), ('copy-out', d2h)):
+        b = union(clip(x))
+        total += b
+        print('%-16s busy %7.2f ms of %7.2f ms = %5.1f %%' % (name, b / 1e6, span / 1e6, 100.0 * b / span))
+    print('calls in the window: %d -> %.3f ms per call; sum of the three busy times = %.2f x the window' % (len(whole) - 3, span / 1e6 / (len(whole) - 3), total / span))
 
 
 if __name__ == '__main__':
