@@ -1340,7 +1340,10 @@ bool Engine::process_host_async(int T, const int16_t *pcm, int16_t *out, std::st
     if (!run_device(T, din, dout, err)) return false;
     ok = hipEventRecord(aev_done_[s], stream_) == hipSuccess;
     ok = ok && hipStreamWaitEvent(copy_out_, aev_done_[s], 0) == hipSuccess;
-    ok = ok && hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, copy_out_) == hipSuccess;
+    // (as a 2-D copy of B_ rows: the runtime hands those to the copy engines; a plain hipMemcpyAsync into page-locked memory went
+    // through its copy KERNEL, which took compute units from the engine's own kernels -- profiles/r05_host_async_trace.txt)
+    ok = ok && hipMemcpy2DAsync(out, (size_t) T * kFrame * 2, dout, (size_t) T * kFrame * 2, (size_t) T * kFrame * 2, B_, hipMemcpyDeviceToHost,
+                                copy_out_) == hipSuccess;
     ok = ok && hipEventRecord(aev_out_[ring], copy_out_) == hipSuccess;
     if (!ok) {
         *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
