@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <memory>
 #include <mutex>
@@ -343,6 +344,13 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     // host-pointer calls are cut into sub-chunks of host_chunk_ frames (two staging slots = the Tmax-sized buffers)
     host_chunk_ = Tmax_ / 2 < 1 ? 1 : (Tmax_ / 2 > 16 ? 16 : Tmax_ / 2);
     host_pipeline_min_bytes_ = (size_t) 4 << 20;  // below this a call is launch-bound: sub-chunks would only add launches
+    if (const char *e = dev_env("KOALA_AMD_HOST_SCHED")) {  // sub-chunk lengths "6,8,12,...": repeated / truncated to the call's frames
+        for (const char *q = e; *q;) {
+            dev_host_sched_.push_back(atoi(q));
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+    }
     if (const char *e = dev_env("KOALA_AMD_HOST_CHUNK")) {  // force a sub-chunk length; 0 = never split
         const int v = atoi(e);
         if (v >= 1 && v <= Tmax_ / 2) host_chunk_ = v, host_pipeline_min_bytes_ = 0;
@@ -1199,23 +1207,55 @@ static void host_copy_2d(void *dst, size_t dpitch, const void *src, size_t spitc
 // Host-pointer call in sub-chunks of host_chunk_ frames: H2D of chunk c+1, the kernels of chunk c and D2H of chunk c-1 run
 // on three streams.  Pinned user buffers (hipHostMalloc / hipHostRegister / pv_koala_batch_host_alloc) are read and written
 // by the copy engines directly (strided 2D copies); pageable ones go through the engine's pinned staging slots.
+// The sub-chunk lengths of a synchronous host call of T frames.  What the caller waits for is
+//   copy-in(first chunk) + sum of the chunks' kernel times + copy-out(last chunk),
+// and a chunk's kernels cost ~0.17 ms of weight-resident prologues whatever its length (16 launches): short chunks at the two ENDS
+// (little exposed copy time), long ones in the middle (few prologues) -- for 64 frames 4 8 12 16 12 8 4 instead of 4 x 16: 57.8 -> 61.6 M
+// frames/s with page-locked buffers (profiles/r05_host_sched.txt; a model with the measured copy rate and K(T) had said 61.5).  No chunk
+// exceeds host_chunk_ (a staging slot).
+std::vector<int> Engine::host_schedule(int T) const {
+    std::vector<int> sched;
+    if (!dev_host_sched_.empty()) {  // developer override: the given lengths, repeated / truncated to T
+        int left = T;
+        for (size_t i = 0; left > 0; ++i) {
+            const int c = std::min(left, std::max(1, std::min(host_chunk_, dev_host_sched_[i % dev_host_sched_.size()])));
+            sched.push_back(c);
+            left -= c;
+        }
+        return sched;
+    }
+    // a ramp of P/4, P/2, 3P/4 frames at either end (as many of its steps as the call has room for), chunks of at most P between them
+    const int P = host_chunk_;
+    int ramp[3] = {std::max(1, P / 4), std::max(1, P / 2), std::max(1, (3 * P) / 4)}, steps = 3;
+    while (steps > 0 && 2 * (ramp[0] + (steps > 1 ? ramp[1] : 0) + (steps > 2 ? ramp[2] : 0)) + P > T) --steps;
+    int ends = 0;
+    for (int i = 0; i < steps; ++i) ends += ramp[i];
+    const int mid = T - 2 * ends, n = (mid + P - 1) / P;
+    for (int i = 0; i < steps; ++i) sched.push_back(ramp[i]);
+    for (int i = 0; i < n; ++i) sched.push_back(mid / n + (i < mid % n ? 1 : 0));
+    for (int i = steps - 1; i >= 0; --i) sched.push_back(ramp[i]);
+    return sched;
+}
+
 bool Engine::process_host_pipelined(int T, const int16_t *pcm, int16_t *out, bool pinned, std::string *err) {
-    const int Tc = host_chunk_;
-    const int n = (T + Tc - 1) / Tc;
-    const size_t row_user = (size_t) T * kFrame * 2;  // pitch of the caller's [B][T * 256] matrices
-    const size_t slot = (size_t) B_ * Tc * kFrame;     // int16 elements per staging slot
+    const std::vector<int> sched = host_schedule(T);
+    const int n = (int) sched.size();
+    std::vector<int> first(n + 1, 0);  // first frame of chunk c
+    for (int c = 0; c < n; ++c) first[c + 1] = first[c] + sched[c];
+    const size_t row_user = (size_t) T * kFrame * 2;           // pitch of the caller's [B][T * 256] matrices
+    const size_t slot = (size_t) B_ * host_chunk_ * kFrame;    // int16 elements per staging slot (the longest chunk fits)
     bool ok = true;
     auto check = [&](hipError_t e) { ok = ok && e == hipSuccess; };
     auto drain_to_user = [&](int c) {  // chunk c's output: staging slot -> caller (pageable path)
-        const int s = c & 1, tc = (c + 1) * Tc <= T ? Tc : T - c * Tc;
+        const int s = c & 1, tc = sched[c];
         check(hipEventSynchronize(ev_out_[s]));
-        host_copy_2d((char *) out + (size_t) c * Tc * kFrame * 2, row_user, h_out_ + s * slot, (size_t) tc * kFrame * 2,
+        host_copy_2d((char *) out + (size_t) first[c] * kFrame * 2, row_user, h_out_ + s * slot, (size_t) tc * kFrame * 2,
                      (size_t) tc * kFrame * 2, B_);
     };
     for (int c = 0; c < n && ok; ++c) {
-        const int s = c & 1, tc = (c + 1) * Tc <= T ? Tc : T - c * Tc;
+        const int s = c & 1, tc = sched[c];
         const size_t width = (size_t) tc * kFrame * 2;
-        const char *src = (const char *) pcm + (size_t) c * Tc * kFrame * 2;
+        const char *src = (const char *) pcm + (size_t) first[c] * kFrame * 2;
         // ---- copy-in (slot s was last read by the kernels of chunk c - 2)
         if (c >= 2) check(hipStreamWaitEvent(copy_in_, ev_done_[s], 0));
         if (pinned) {
@@ -1240,7 +1280,7 @@ bool Engine::process_host_pipelined(int T, const int16_t *pcm, int16_t *out, boo
         // ---- copy-out
         check(hipStreamWaitEvent(copy_out_, ev_done_[s], 0));
         if (pinned) {
-            check(hipMemcpy2DAsync((char *) out + (size_t) c * Tc * kFrame * 2, row_user, d_out_ + s * slot, width, width, B_,
+            check(hipMemcpy2DAsync((char *) out + (size_t) first[c] * kFrame * 2, row_user, d_out_ + s * slot, width, width, B_,
                                    hipMemcpyDeviceToHost, copy_out_));
         } else {
             if (c >= 2) drain_to_user(c - 2);  // frees staging slot s

@@ -107,6 +107,8 @@ private:
     int16_t *d_in_ = nullptr, *d_out_ = nullptr, *h_in_ = nullptr, *h_out_ = nullptr;
     // host-pointer calls with more than one sub-chunk: copy-in, compute and copy-out run on three streams
     bool process_host_pipelined(int T, const int16_t *pcm, int16_t *out, bool pinned, std::string *err);
+    std::vector<int> host_schedule(int T) const;  // its sub-chunk lengths
+    std::vector<int> dev_host_sched_;             // developer override (KOALA_AMD_HOST_SCHED)
     // calls of several frames as a wavefront over (stage, frame): kns_engine.cpp, run_wave
     GruSmallArgs small_args(int mtb, const void *a0, int nb0, const void *a1, const void *wih, const float *bih, const void *whh,
                             const float *bhh, int layer, void *hseq, int t, const StageDev *head) const;

@@ -96,7 +96,7 @@ def test_product_library_reads_no_developer_switch(native_library):
     blob = open(native_library, 'rb').read()
     dev = open(koala_amd.developer_library_path(), 'rb').read()
     for name in (b'KOALA_AMD_ONLY_CLASS', b'KOALA_AMD_GRU_STREAM', b'KOALA_AMD_GEMM_GENERIC', b'KOALA_AMD_SMALL_MT',
-                 b'KOALA_AMD_DEBUG_TAPS', b'KOALA_AMD_HOST_CHUNK'):
+                 b'KOALA_AMD_DEBUG_TAPS', b'KOALA_AMD_HOST_CHUNK', b'KOALA_AMD_HOST_SCHED', b'KOALA_AMD_NO_SPIN_WAIT'):
         assert name not in blob, name
         assert name in dev, name
     assert b'KOALA_AMD_PRECISION' in blob  # the one documented run-time option of the single-stream ABI

@@ -263,12 +263,16 @@ def test_host_call_in_place_through_the_pipelined_path(random_model):
 
 
 @pytest.mark.parametrize('B,Tmax,T,chunk', [(33, 32, 32, '16'), (33, 32, 21, '16'), (20, 8, 7, '4'), (48, 16, 16, '3'),
-                                            (16, 32, 32, '0'), (5, 2, 2, '1')])
+                                            (16, 32, 32, '0'), (5, 2, 2, '1'), (33, 64, 64, '16'), (21, 64, 57, '16:5,7,16,3')])
 def test_host_pointer_calls_are_pipelined_without_changing_results(random_model, monkeypatch, B, Tmax, T, chunk):
     """Host-pointer calls run as overlapping sub-chunks (pageable buffers through staging slots, page-locked ones by direct
     strided copies): both must equal the device-pointer call bit for bit, across calls and for ragged chunk counts."""
     torch = pytest.importorskip('torch')
-    monkeypatch.setenv('KOALA_AMD_HOST_CHUNK', chunk)  # small calls are not split unless told to
+    # small calls are not split unless told to; 'chunk:a,b,c' also dictates the sub-chunk lengths (default: short chunks at both ends of
+    # the call, long ones in the middle -- Engine::host_schedule)
+    monkeypatch.setenv('KOALA_AMD_HOST_CHUNK', chunk.split(':')[0])
+    if ':' in chunk:
+        monkeypatch.setenv('KOALA_AMD_HOST_SCHED', chunk.split(':')[1])
     x = synth_streams(B, 2 * T, seed=5)
     kb = koala_amd.create_batch('key', B, Tmax, 'bf16', model_path=random_model, library_path=DEV_LIB)
     dx = torch.from_numpy(x).cuda()
