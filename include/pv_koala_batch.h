@@ -50,11 +50,16 @@ PV_API pv_status_t pv_koala_batch_process_chunk(pv_koala_batch_t *object, int32_
  * PV_STATUS_RUNTIME_ERROR, nothing processed).  The call enqueues its copy-in, kernels and copy-out and RETURNS; up to three such calls are
  * in flight per handle (a fourth first waits for the oldest), so one call's copies run under its neighbours' kernels -- a synchronous
  * call cannot hide its first copy-in and last copy-out.  Calls complete in order; `enhanced` of a call is valid, and `pcm` may be
- * reused, once pv_koala_batch_synchronize() has returned or three further asynchronous calls have been accepted (a caller rotating
- * over three buffer pairs keeps both directions of the link and the GPU busy at once).  Every other entry
+ * reused, once pv_koala_batch_synchronize() or pv_koala_batch_async_wait() says the call has completed (a caller rotating over three
+ * buffer pairs keeps both directions of the link and the GPU busy at once).  Every other entry
  * point of the handle first waits for the calls in flight.  `enhanced` may equal `pcm`. */
 PV_API pv_status_t pv_koala_batch_process_chunk_async(pv_koala_batch_t *object, int32_t num_frames, const int16_t *pcm,
                                                       int16_t *enhanced);
+
+/* Blocks until at most `max_in_flight` asynchronous calls of the handle are still in flight (0: all have completed; calls complete in
+ * order).  The triple-buffering loop of a host caller:  for call n:  pv_koala_batch_async_wait(o, 2)  -- call n - 3 is complete: take its
+ * `enhanced`, refill its `pcm` --  then pv_koala_batch_process_chunk_async(o, frames, pcm[n % 3], enhanced[n % 3]). */
+PV_API pv_status_t pv_koala_batch_async_wait(pv_koala_batch_t *object, int32_t max_in_flight);
 
 /* Resets the streams whose byte in `stream_mask[num_streams]` (host memory) is non-zero; NULL resets all. */
 PV_API pv_status_t pv_koala_batch_reset(pv_koala_batch_t *object, const uint8_t *stream_mask);

@@ -33,7 +33,7 @@ class KoalaBatch(object):
         lib.pv_koala_batch_init.argtypes = [c_char_p, c_char_p, c_char_p, c_int32, c_int32, c_int32, POINTER(c_void_p)]
         lib.pv_koala_batch_init.restype = PicovoiceStatuses
         for name, args in (('process_chunk', [c_void_p, c_int32, c_void_p, c_void_p]), ('process_chunk_async', [c_void_p, c_int32, c_void_p, c_void_p]),
-                           ('reset', [c_void_p, c_void_p]),
+                           ('async_wait', [c_void_p, c_int32]), ('reset', [c_void_p, c_void_p]),
                            ('set_stream', [c_void_p, c_void_p]), ('synchronize', [c_void_p]),
                            ('profile_enable', [c_void_p, c_int32]),
                            ('profile_read', [c_void_p, POINTER(c_double), POINTER(c_int64)]),
@@ -103,7 +103,7 @@ class KoalaBatch(object):
     def process_async(self, pcm: np.ndarray, enhanced: np.ndarray) -> None:
         """`process_into()` without the wait, for page-locked arrays (`alloc_host()`): the call is enqueued and returns; up to three are
         in flight, so a caller that rotates over three buffer pairs keeps the link and the GPU busy at once.  `enhanced` is valid
-        after `synchronize()` (or once three further asynchronous calls have been accepted)."""
+        after `synchronize()` or once `wait(k)` says the call is no longer among the k in flight."""
         for a in (pcm, enhanced):
             if (not isinstance(a, np.ndarray) or a.dtype != np.int16 or not a.flags['C_CONTIGUOUS'] or a.ndim != 2 or
                     a.shape[0] != self.num_streams or a.shape[1] % self.frame_length or a.shape != pcm.shape):
@@ -111,6 +111,11 @@ class KoalaBatch(object):
                     "expected C-contiguous int16 arrays of shape [%d, T*%d]" % (self.num_streams, self.frame_length))
         self._check(self._lib.pv_koala_batch_process_chunk_async(self._handle, pcm.shape[1] // self.frame_length,
                                                                  pcm.ctypes.data, enhanced.ctypes.data), 'Processing failed')
+
+    def wait(self, max_in_flight: int = 0) -> None:
+        """Blocks until at most `max_in_flight` asynchronous calls are still in flight (0: all done).  Triple buffering: before reusing
+        buffer pair n % 3 for call n, `wait(2)` -- call n - 3 has completed, its output may be taken and its input refilled."""
+        self._check(self._lib.pv_koala_batch_async_wait(self._handle, max_in_flight), 'wait failed')
 
     def process_device(self, num_frames: int, pcm_ptr: int, enhanced_ptr: int) -> None:
         """Device pointers (e.g. torch_tensor.data_ptr()) of int16 [num_streams, num_frames*256]; asynchronous."""

@@ -1319,6 +1319,21 @@ bool Engine::drain_async(std::string *err) {
     return ok;
 }
 
+bool Engine::async_wait(int max_in_flight, std::string *err) {
+    if (max_in_flight <= 0) return drain_async(err);
+    for (int j = 3; j > max_in_flight; --j) {  // the calls async_n_ - 3 ... async_n_ - max_in_flight - 1, oldest first
+        if ((unsigned) j > async_n_) continue;
+        const int ring = (int) ((async_n_ - (unsigned) j) & 3u);
+        if (!async_busy_[ring]) continue;
+        if (hipEventSynchronize(aev_out_[ring]) != hipSuccess) {
+            *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
+            return false;
+        }
+        async_busy_[ring] = false;
+    }
+    return true;
+}
+
 // One asynchronous host call = H2D on copy_in_, the kernels on the handle's stream, D2H on copy_out_, chained by events.  Up to
 // THREE calls are in flight: with two, a caller alternating between two buffer pairs cannot issue call n + 2 before call n's copy-out has
 // finished, which puts a slot's copy-in, kernels and copy-out in series (measured: 4.03 ms per 4096 x 64 frames = (2.8 + 2.6 + 2.8) / 2);

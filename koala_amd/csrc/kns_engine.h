@@ -49,6 +49,7 @@ public:
     // for all of them.
     bool process_host_async(int T, const int16_t *pcm, int16_t *out, std::string *err);
     bool drain_async(std::string *err);
+    bool async_wait(int max_in_flight, std::string *err);  // until at most that many asynchronous calls are still in flight (0: all done)
     bool reset(const uint8_t *host_mask, std::string *err);
     void set_stream(hipStream_t s) { stream_ = s ? s : own_stream_; }
     bool synchronize(std::string *err);

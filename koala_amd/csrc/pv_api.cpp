@@ -453,6 +453,26 @@ PV_API pv_status_t pv_koala_batch_process_chunk_async(pv_koala_batch_t *object, 
     });
 }
 
+PV_API pv_status_t pv_koala_batch_async_wait(pv_koala_batch_t *object, int32_t max_in_flight) {
+    t_stack.clear();
+    if (!object) {
+        push_error(0x64, "Argument `object` is NULL.");
+        return PV_STATUS_INVALID_ARGUMENT;
+    }
+    if (max_in_flight < 0) {
+        push_error(0x66, "`max_in_flight` %d is negative.", max_in_flight);
+        return PV_STATUS_INVALID_ARGUMENT;
+    }
+    return guarded([&] {
+        std::string err;
+        if (!object->engine->async_wait(max_in_flight, &err)) {
+            push_error(0x33B, "%s", err.c_str());
+            return PV_STATUS_RUNTIME_ERROR;
+        }
+        return PV_STATUS_SUCCESS;
+    });
+}
+
 PV_API pv_status_t pv_koala_batch_process(pv_koala_batch_t *object, const int16_t *pcm, int16_t *enhanced) {
     return pv_koala_batch_process_chunk(object, 1, pcm, enhanced);
 }

@@ -58,7 +58,7 @@ def enhance_single(koala, pcm):
     return np.array(out, np.int16)
 
 
-def enhance_batch(batch, signals, frames_per_call):
+def enhance_batch(batch, signals, frames_per_call, asynchronous=False):
     """Many utterances at once: each is one stream of the batch, zero-padded to the longest; same trimming."""
     n, delay = batch.frame_length, batch.delay_sample
     longest = max(len(s) for s in signals)
@@ -67,8 +67,25 @@ def enhance_batch(batch, signals, frames_per_call):
     x = np.zeros((batch.num_streams, total_frames * n), np.int16)
     for i, s in enumerate(signals):
         x[i, :len(s)] = s
-    y = np.concatenate([batch.process(np.ascontiguousarray(x[:, c * n:(c + frames_per_call) * n]))
-                        for c in range(0, total_frames, frames_per_call)], axis=1)
+    calls = list(range(0, total_frames, frames_per_call))
+    if asynchronous:
+        # three page-locked buffer pairs in rotation (pv_koala_batch_process_chunk_async): call n's copies run under its neighbours'
+        # kernels; before pair n % 3 is reused, wait(2) guarantees that call n - 3 has completed and its output can be taken
+        pairs = [(batch.alloc_host(frames_per_call), batch.alloc_host(frames_per_call)) for _ in range(3)]
+        outs = []
+        for i, c in enumerate(calls):
+            a, b = pairs[i % 3]
+            if i >= 3:
+                batch.wait(2)
+                outs.append(b.copy())
+            a[:] = x[:, c * n:(c + frames_per_call) * n]
+            batch.process_async(a, b)
+        batch.wait(0)
+        for i in range(max(0, len(calls) - 3), len(calls)):
+            outs.append(pairs[i % 3][1].copy())
+        y = np.concatenate(outs, axis=1)
+    else:
+        y = np.concatenate([batch.process(np.ascontiguousarray(x[:, c * n:(c + frames_per_call) * n])) for c in calls], axis=1)
     return [y[i, delay:delay + len(s)] for i, s in enumerate(signals)]
 
 
@@ -83,6 +100,7 @@ def main():
     p.add_argument('--device', default='best')
     p.add_argument('--frames_per_call', type=int, default=32)
     p.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'])
+    p.add_argument('--asynchronous', action='store_true', help='many-files mode: asynchronous calls over three page-locked buffer pairs')
     p.add_argument('--show_inference_devices', action='store_true')
     args = p.parse_args()
     if args.show_inference_devices:
@@ -111,7 +129,7 @@ def main():
         try:
             signals = [read_wav(pth, batch.sample_rate) for pth in args.input_path]
             t0 = time.perf_counter()
-            outs = enhance_batch(batch, signals, args.frames_per_call)
+            outs = enhance_batch(batch, signals, args.frames_per_call, args.asynchronous)
             dt = time.perf_counter() - t0
             for pth, o in zip(args.input_path, outs):
                 write_wav(os.path.join(args.output_dir, os.path.basename(pth)), o, batch.sample_rate)

@@ -58,6 +58,7 @@ bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err, 
 }
 bool Engine::process_host_async(int T, const int16_t *pcm, int16_t *out, std::string *err) { return process(T, pcm, out, err, true); }
 bool Engine::drain_async(std::string *) { return true; }
+bool Engine::async_wait(int, std::string *) { return true; }
 bool Engine::reset(const uint8_t *, std::string *) { return true; }
 bool Engine::synchronize(std::string *) { return true; }
 void Engine::profile_enable(bool on) { profiling_ = on; }

@@ -162,6 +162,14 @@ def test_file_demo_cli_single_and_batch(gate_model, tmp_path):
     a, b = samples(single), samples(outdir / 'test.wav')
     assert len(a) == len(b) == 93680 and np.array_equal(a, b)
     assert frame_rms(samples(outdir / 'noise.wav')) < 0.01
+    # ... and the many-files mode over asynchronous calls (three page-locked buffer pairs, pv_koala_batch_async_wait): the same samples
+    outdir2 = tmp_path / 'many_async'
+    r = subprocess.run([sys.executable, '-m', 'koala_amd.demo.koala_demo_file', '--input_path',
+                        GOLDEN + '/test.wav', GOLDEN + '/noise.wav', '--output_dir', str(outdir2), '--model_path',
+                        gate_model, '--frames_per_call', '16', '--asynchronous'], capture_output=True, text=True, env=env, cwd=ROOT)
+    assert r.returncode == 0 and 'Real time factor' in r.stdout, r.stderr
+    for name in ('test.wav', 'noise.wav'):
+        assert np.array_equal(samples(outdir2 / name), samples(outdir / name)), name
 
 
 def test_stream_demo_matches_the_frame_loop(gate_model, tmp_path):
