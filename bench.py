@@ -284,6 +284,20 @@ def cpu_leg_child(T, distinct):
                       'build': '-O3 -march=native (this host)' if native.endswith('_native.so') else '-O3 -march=x86-64-v3'}))
 
 
+def host_busy_fraction(seconds):
+    """share of all host cores' time that was not idle over the next `seconds` (/proc/stat, first line)"""
+    def read():
+        v = [int(x) for x in open('/proc/stat').readline().split()[1:]]
+        return sum(v), v[3] + (v[4] if len(v) > 4 else 0)  # total, idle + iowait
+    try:
+        t0, i0 = read()
+        time.sleep(seconds)
+        t1, i1 = read()
+        return 1.0 - (i1 - i0) / max(1, t1 - t0)
+    except Exception:
+        return 0.0
+
+
 def machine_state():
     """What resources/scripts/machine-state.sh of the reference logs around its perf runs: load and memory."""
     st = {}
@@ -648,15 +662,18 @@ def main():
         # per physical core, bound (OMP_PLACES=cores, OMP_PROC_BIND=close: a block's scratch is first touched, hence allocated, on the
         # NUMA node of the core that works on it), no torch thread pools beside it -- on the oracle compiled for THIS host's instruction
         # set (-march=native, built here and now; the parity checks below use the portable build that travels with the repository:
-        # same source, same results bit for bit).  It starts once the box is quiet -- the 1-minute load average below 4, waited for at
-        # most 45 s (it decays with a 60 s time constant: after the GPU legs' host threads it starts around 15-30); a leg that had
-        # to start on a busy box says so: "noisy": true.
+        # same source, same results bit for bit).  It starts once the box is quiet (below), waited for at most 45 s; a leg that had to start on a busy box
+        # says so: "noisy": true.
+        # (quiet = the host's cores at least 97 % idle over the last second, read from /proc/stat: the 1-minute load average this used to
+        # wait for decays with a 60 s time constant and still reads 20-60 minutes after the load -- this run's own start-up -- is gone)
         t_wait = time.perf_counter()
-        while machine_state().get('loadavg_1m', 0.0) >= 4.0 and time.perf_counter() - t_wait < 45.0:
-            time.sleep(1.0)
+        busy = host_busy_fraction(1.0)
+        while busy >= 0.03 and time.perf_counter() - t_wait < 45.0:
+            busy = host_busy_fraction(1.0)
         waited = time.perf_counter() - t_wait
         before = machine_state()
         before['waited_for_quiet_s'] = round(waited, 1)
+        before['host_busy_fraction_last_second'] = round(busy, 4)
         phys = physical_cores()
         env = dict(os.environ, OMP_PLACES='cores', OMP_PROC_BIND='close', OMP_NUM_THREADS=str(phys), OMP_DYNAMIC='false')
         env.pop('KNS_ORACLE_JITTER', None)
@@ -665,7 +682,7 @@ def main():
         leg = json.loads(child.stdout.decode().strip().splitlines()[-1])
         cpu = {'value': leg['frames_per_s'], 'unit': 'frames/s', 'cores': leg['threads'], 'kind': 'port',
                'host_logical_cpus': ncores, 'binding': 'OMP_PLACES=cores OMP_PROC_BIND=close, one thread per physical core, own process',
-               'noisy': bool(before.get('loadavg_1m', 0.0) >= 4.0),
+               'noisy': bool(busy >= 0.03),
                'one_thread_frames_per_s': leg['one_thread_frames_per_s'], 'scaling_vs_1_thread': round(leg['frames_per_s'] / leg['one_thread_frames_per_s'], 1),
                'build': leg['build'],
                'sample': '%d streams x %d frames of the same synthetic workload, oracle/kns_oracle.c fp32 (register-blocked '
