@@ -142,13 +142,17 @@ def test_overlapping_host_buffers_are_refused_where_the_call_is_pipelined(lib, r
     lib.pv_koala_batch_delete(h)
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
-def test_asynchronous_host_calls_equal_the_synchronous_path(random_model, precision):
+@pytest.mark.parametrize('precision,own_stream', [('fp32', True), ('bf16', True), ('bf16', False)])
+def test_asynchronous_host_calls_equal_the_synchronous_path(random_model, precision, own_stream):
     """pv_koala_batch_process_chunk_async: two calls in flight, copies under the neighbours' kernels -- the same samples, bit for bit,
     as the same calls made synchronously; calls of different lengths, an in-place call, a reset and a synchronous call in between."""
     B, Tmax = 70, 12
     ka = koala_amd.create_batch('key', B, Tmax, precision, model_path=random_model)
     ks = koala_amd.create_batch('key', B, Tmax, precision, model_path=random_model)
+    if not own_stream:  # the kernels on a caller's stream: the copy streams hang off it by events all the same
+        import torch
+        side = torch.cuda.Stream()
+        ka.set_stream(side.cuda_stream)
     lens = [12, 5, 12, 1, 7, 12, 3]
     xs = [synth_streams(B, t, seed=900 + i) for i, t in enumerate(lens)]
     want = []
