@@ -754,3 +754,74 @@ def test_bf16_features_are_the_oracles_bits(random_model, monkeypatch, B, T):
         for t in range(T):
             _, tp = o.process_tap(x[b, t * 256:(t + 1) * 256])
             assert np.array_equal(got[t, b], _round_bf16(tp['features'])), (b, t)
+
+
+def _envelope_ok(out, want):
+    """The reference's acceptance criterion (binding/python/test_koala.py:71-114): per-frame RMS of the enhanced signal within 0.02 of the
+    RMS of the expected one, one frame (the engine's delay) later; `want` None = pure noise in: every frame's RMS below 0.02."""
+    def rms(a):
+        return np.sqrt(np.mean((a.reshape(-1, 256).astype(np.float64) / 32768.0) ** 2, axis=1))
+    o = rms(out)
+    dev = o.copy() if want is None else np.concatenate([o[:1], np.abs(o[1:] - rms(want)[:-1])])
+    return float(dev.max())
+
+
+@pytest.mark.parametrize('name', ['test', 'noise', 'mixed'])
+def test_bf16_single_stream_abi_on_reference_wavs(gate_model, random_model, test_pcm, noise_pcm, monkeypatch, name):
+    """pv_koala_init / pv_koala_process with KOALA_AMD_PRECISION=bf16 -- the entry path BASELINE configs[4]'s bf16 latency is quoted on
+    (pv_api.cpp default_precision(); hipGraph replay of the one-frame pipeline) -- on resources/audio_samples, default and random
+    model: the first half of the file, ONE pv_koala_reset in the middle of the signal, then the whole file.  Every frame against the
+    oracle with the same rounding points driven through the same sequence (the suite's bf16 bars); after the reset the first half must
+    come out exactly as before it (the reference's test_reset, binding/python/test_koala.py:116-129); and on the default model the
+    whole-file pass meets the reference's envelope (binding/python/test_koala.py:71-114)."""
+    monkeypatch.setenv('KOALA_AMD_PRECISION', 'bf16')
+    pcm = {'test': test_pcm, 'noise': noise_pcm,
+           'mixed': np.clip(test_pcm.astype(int) + noise_pcm, -32768, 32767).astype(np.int16)}[name]
+    nfr = len(pcm) // 256
+    n, cut = nfr * 256, (nfr // 2) * 256
+    for model in (gate_model, random_model):
+        k = koala_amd.create('key', model_path=model, device='gpu:0')
+        head = np.concatenate([np.array(k.process(pcm[i:i + 256]), np.int16) for i in range(0, cut, 256)])
+        k.reset()  # in the middle of the signal: frame cut / 256 is never seen by the first pass
+        out = np.concatenate([np.array(k.process(pcm[i:i + 256]), np.int16) for i in range(0, n, 256)])
+        k.delete()
+        o = oracle.Oracle(model, 1, oracle.PREC_BF16)
+        ref_head = o.process(pcm[None, :cut])[0]
+        o.reset()
+        ref = o.process(pcm[None, :n])[0]
+        d = lsb(np.concatenate([head, out]), np.concatenate([ref_head, ref]))
+        print('%s, %s: max %d LSB, %.4f %% within 1' % (name, 'default' if model == gate_model else 'random', int(d.max()),
+                                                         100.0 * (d <= 1).mean()))
+        assert d.max() <= BF16_TOL, int(d.max())
+        assert (d <= 1).mean() >= (BF16_DEFAULT_MODEL_WITHIN_1 if model == gate_model else BF16_WITHIN_1)
+        assert np.array_equal(out[:cut], head)  # reset == new instance, bit for bit
+        if model == random_model and name != 'noise':  # and not the fp32 engine by accident: its samples are the fp32 oracle's
+            assert not np.array_equal(head, run_oracle(model, pcm[None, :cut])[0])
+        if model == gate_model:
+            assert _envelope_ok(out, {'test': test_pcm, 'noise': None, 'mixed': test_pcm}[name][:n] if name != 'noise' else None) < 0.02
+
+
+def test_baseline_config2_b4096_t64_bf16_at_its_exact_shape(random_model):
+    """BASELINE configs[2] exactly as bench.py times it: 4 096 streams x 64 frames per call, bf16 GEMMs + fp32 FFT, device pointers --
+    two consecutive calls, 512 distinct streams (every one of them against the bf16-rounding oracle; the other slots hold replicas
+    that must be bit-identical), and the bench line's distribution bar (>= 99.9 % of the samples within 1 LSB)."""
+    torch = pytest.importorskip('torch')
+    B, T, distinct = 4096, 64, 512
+    base = synth_streams(distinct, 2 * T, seed=4096)
+    kb = koala_amd.create_batch('key', B, T, 'bf16', model_path=random_model)
+    ref = oracle.Oracle(random_model, distinct, oracle.PREC_BF16)
+    for c in range(2):
+        chunk = np.ascontiguousarray(base[:, c * T * 256:(c + 1) * T * 256])
+        dx = torch.from_numpy(np.tile(chunk, (B // distinct, 1))).cuda()
+        dy = torch.zeros_like(dx)
+        torch.cuda.synchronize()
+        kb.process_device(T, dx.data_ptr(), dy.data_ptr())
+        kb.synchronize()
+        y = dy.cpu().numpy()
+        d = lsb(y[:distinct], ref.process(chunk))
+        hist = np.bincount(np.minimum(d.ravel(), 8), minlength=9)
+        print('4096 x 64 bf16, call %d: |gpu - oracle| histogram 0..8+: %s' % (c, hist.tolist()))
+        assert d.max() <= BF16_TOL, (c, int(d.max()))
+        assert (d <= 1).mean() >= 0.999, (c, float((d <= 1).mean()))
+        assert np.array_equal(y.reshape(B // distinct, distinct, -1), np.broadcast_to(y[:distinct], (B // distinct, distinct, y.shape[1])))
+    kb.delete()
