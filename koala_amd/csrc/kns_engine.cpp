@@ -318,7 +318,7 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     no_zero_copy_ = dev_env("KOALA_AMD_NO_ZERO_COPY") != nullptr;
     no_recompute_ = dev_env("KOALA_AMD_STORE_SPECTRUM") != nullptr;  // A/B switch: spectrum through HBM in every call
     debug_taps_ = dev_env("KOALA_AMD_DEBUG_TAPS") != nullptr;        // keep every intermediate debug_read() can return
-    dev_variant_ = (dev_env("KOALA_AMD_GRU_STREAM") ? kDevGruStream : 0) | (dev_env("KOALA_AMD_GRU_BARRIER") ? kDevGruBarrier : 0) | (dev_env("KOALA_AMD_GEMM_GENERIC") ? kDevGemmGeneric : 0) |
+    dev_variant_ = (dev_env("KOALA_AMD_GRU_STREAM") ? kDevGruStream : 0) | (dev_env("KOALA_AMD_GEMM_GENERIC") ? kDevGemmGeneric : 0) |
                    (dev_env("KOALA_AMD_GEMM_NO_WSR") ? kDevGemmNoWsr : 0);
     auto dev_int = [](const char *name, int dflt) {
         const char *e = dev_env(name);

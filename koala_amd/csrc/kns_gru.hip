@@ -615,9 +615,6 @@ void launch_gru_small(const GruSmallArgs &a, hipStream_t s) {
 // (round 4: the first 14 of tile w and all 27 of tile w + 8), 13 in LDS, tile 16 in LDS: 328 KiB of registers + 131 KiB of LDS.
 // A fragments are re-read from LDS per k-block.
 constexpr int kR8Waves = 8;
-#ifndef R8_FLAGS
-#define R8_FLAGS 0  // 1: per-tile step counters instead of the barrier (round 6: measured slower, profiles/r06_antiphase.txt)
-#endif
 #ifndef R8C_Q
 #define R8C_Q 3
 #endif
@@ -642,63 +639,37 @@ constexpr int kR8HeadLds = PBF16::NBH * 1024;          // (kYHead) the narrow he
 // MFMAs of one unit tile whose fragments [first_lds, 27) live in LDS at wl[(i - first_lds)] (i = k_block * 3 + gate) and
 // the rest in wreg[i]; LDS fragments go through a kQ-deep register queue
 // kChain: a fourth accumulator rides along, one link per k-block with the same A fragment -- w16[blk * kChainStride * 64]
-// The operand's A fragments are requested R8_APF k-blocks AHEAD of the MFMAs that multiply them (round 6: with the read issued right in
-// front of its three MFMAs every k-block exposed an LDS round trip, ~100 cycles against 48 cycles of matrix work)
+// The operand's A fragments are requested D k-blocks AHEAD of the MFMAs that multiply them (round 6: with the read issued right in
+// front of its three MFMAs every k-block exposed an LDS round trip; -1.5 ... -2 % per launch, profiles/r06_antiphase.txt section 2)
 #ifndef R8_APF
 #define R8_APF 2  // gru_resident8_kernel<false> (six of the bench's eight recurrent launches): fits 256 registers without a spill
 #endif
 #ifndef R8_APF_Y
-#define R8_APF_Y 0  // gru_resident8_kernel<true>: the head's chain and epilogue leave no registers for it (a distance of 1 spills inside the step)
+#define R8_APF_Y 0  // gru_resident8_kernel<true>: the head's chain and epilogue leave no registers (a distance of 1 spills inside the step)
 #endif
-// kGate < NBH: the hidden vector's k-blocks kGate ... are not known to be complete when the loop starts -- `gate()` (a wait on the
-// producers' step counters, gru_resident8_kernel<.., true>) runs in front of the first request for them, and nothing is requested across it
-struct R8NoGate {
-    __device__ __forceinline__ void operator()() const {}
-};
-#ifndef R8_APF_F
-#define R8_APF_F 1
-#endif
-#ifndef R8_APF_FY
-#define R8_APF_FY 0
-#endif
-template <int kFirstLds, int kQ, int kNReg, bool kChain = false, int kChainStride = 3, int D = 0, int kGate = PBF16::NBH, class Gate = R8NoGate>
+template <int kFirstLds, int kQ, int kNReg, bool kChain = false, int kChainStride = 3, int D = 0>
 __device__ __forceinline__ void r8_tile_mma(f32x4 (&acc)[3], const bf16x8 *ha, const bf16x8 (&wreg)[kNReg], const bf16x8 *wl,
-                                            int lane, f32x4 *a16 = nullptr, const bf16x8 *w16 = nullptr, Gate gate = Gate()) {
+                                            int lane, f32x4 *a16 = nullptr, const bf16x8 *w16 = nullptr) {
     constexpr int N = 27, NB = PBF16::NBH;
     bf16x8 qb[kQ], qc, aq[D + 1];
+    // (the order of these first requests decides hipcc's register allocation of the whole step: A first with D > 0, last with D = 0 --
+    // the other order spills 20-32 bytes inside the step in either form)
+    if (D > 0) {
 #pragma unroll
-    for (int p = 0; p <= D; ++p)
-        if (p < kGate) aq[p] = ha[p * 64 + lane];
+        for (int p = 0; p <= D; ++p) aq[p] = ha[p * 64 + lane];
+    }
 #pragma unroll
     for (int p = 0; p < kQ; ++p)
         if (kFirstLds + p < N) qb[p] = wl[p * 64 + lane];
     if (kChain) qc = w16[0];
+    if (D == 0) aq[0] = ha[lane];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const int blk = i / 3;
-        if (i % 3 == 0 && blk == kGate) {
-            gate();
-#pragma unroll
-            for (int b = blk; b <= blk + D; ++b)
-                if (b < NB) aq[b % (D + 1)] = ha[b * 64 + lane];
-        } else if (i % 3 == 0 && blk > 0 && blk + D < NB && !(blk < kGate && blk + D >= kGate)) {
-#ifndef R8_T_NOA
-            aq[(blk + D) % (D + 1)] = ha[(blk + D) * 64 + lane];
-#endif
-        }
-#ifdef R8_T_NOA  // TIMING ONLY (garbage): every k-block multiplies the first A fragment -- what do the operand reads cost?
-        const bf16x8 a = aq[0];
-#else
+        if (i % 3 == 0 && blk > 0 && blk + D < NB) aq[(blk + D) % (D + 1)] = ha[(blk + D) * 64 + lane];
         const bf16x8 a = aq[blk % (D + 1)];
-#endif
         bf16x8 b;
-#ifdef R8_T_NOQ  // TIMING ONLY (garbage): the LDS-resident weight fragments replaced by register-resident ones
-        if (true) {
-            b = wreg[i % kNReg];
-        } else if (i < kFirstLds) {
-#else
         if (i < kFirstLds) {
-#endif
             b = wreg[i < kNReg ? i : 0];
         } else {
             const int j = i - kFirstLds;
@@ -722,25 +693,13 @@ __device__ __forceinline__ f16x4 buf_load_gi(__amdgpu_buffer_rsrc_t r, unsigned 
 // (profiles/r04_recurrent_stamps.txt) -- carries its nine MFMAs through its first tile's loop as a fourth accumulator, on the same A
 // fragments (the image of h_{t-1} it multiplies anyway), then the sigmoid and sixteen 2-byte stores: y_{t-1} leaves one step late,
 // y_{T-1} after the loop.  The chain is k-ascending from 0 with the bias after, like gemm_head_kernel's: the same bits.
-//
-// kFlags (round 6): NO barrier in the step.  Every wave publishes a step counter per unit tile behind its LDS image of the new hidden
-// values (`ready`: [wave][2] for tiles w and w + 8, [16 + r] for row group r of tile 16; LDS operations of one wave complete in
-// order, so whoever reads the counter reads the values), and the step's first MFMA loop waits twice: for tiles 0 .. 11 (k-blocks
-// 0 .. 5: every wave's first tile and the second tile of waves 0 .. 3, all long done) before it starts, and for tiles 12 .. 16
-// (k-blocks 6 .. 8: the second tile of waves 4 .. 7 -- the SIMD's second-priority waves, last through the step -- and tile 16's
-// rows) in front of k-block 6.  The chains stay k-ascending: the same bits.  A wave that is through its step no longer idles at
-// a barrier until the slowest one arrives but runs 18 of its next 27 MFMAs beside its SIMD partner's gate arithmetic, and the
-// partner in turn meets gate arithmetic, not a second MFMA loop, when it gets there: the two waves of a SIMD run one window
-// apart by construction.  Write-after-read on the two hidden-state buffers needs nothing further: a wave writes h_{t+1} only
-// after its own first loop of step t + 1, which has seen every counter of step t, i.e. every read of h_{t-1} retired.  The
-// hidden-sequence copy of h_{t-1} moves behind that loop for the same reason (it reads all of it).
-template <bool kYHead, bool kFlags>
+template <bool kYHead>
 __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs g) {
     typedef PBF16 P;
     typedef P::frag_t frag_t;
     constexpr int NBH = P::NBH;
-    constexpr int kApf = kFlags ? (kYHead ? R8_APF_FY : R8_APF_F) : kYHead ? R8_APF_Y : R8_APF;  // A fragments requested this many k-blocks ahead
-    __shared__ __attribute__((aligned(16))) char smem[kR8Lds + 3 * 1024 + 16 + (kYHead ? kR8HeadLds : 0) + (kFlags ? 128 : 0)];
+    constexpr int kApf = kYHead ? R8_APF_Y : R8_APF;  // A fragments requested this many k-blocks ahead
+    __shared__ __attribute__((aligned(16))) char smem[kR8Lds + 3 * 1024 + 16 + (kYHead ? kR8HeadLds : 0)];
     frag_t *wlh = (frag_t *) (smem + kR8Lds + 3 * 1024 + 16);  // (kYHead) [9][64]: the head's n-tile 0
     char *hbuf0 = smem, *hbuf1 = smem + NBH * 1024;
     frag_t *wl1 = (frag_t *) (smem + 2 * NBH * 1024);                                   // [8 waves][13][64]: first tile's, then second tile's
@@ -771,33 +730,6 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     // flags accessed with explicit ds instructions: a volatile access or a workgroup fence would make hipcc drain every
     // outstanding global load of the wave (s_waitcnt vmcnt(0)) first
     const unsigned flag16 = (unsigned) (uintptr_t) (smem + kR8Lds + 3 * 1024);  // [3 gates]: step count of acc16's content
-    // (kFlags) ready[32]: steps completed per (wave, tile) / tile-16 row group; entries 20 .. 31 are never waited for
-    const unsigned ready = (unsigned) (uintptr_t) (smem + kR8Lds + 3 * 1024 + 16 + (kYHead ? kR8HeadLds : 0));
-    const unsigned ready_lane = ready + (lane & 31) * 4;
-    constexpr unsigned long long kEarly = 0x55ffull, kAll = 0xfffffull;  // tiles 0 .. 11 | all seventeen
-    // (one asm block, not a C loop: with a loop in the middle of the unrolled MFMA sequence hipcc's register allocation of the
-    // whole step changed -- 23 to 57 spilled registers, four weight fragments reloaded from scratch every step)
-    auto wait_ready = [&](int steps, unsigned long long mask) {
-        int v;
-        asm volatile(
-            "Lr8_wait_%=:\n\t"
-            "ds_read_b32 %0, %1\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            "v_cmp_le_i32 vcc, %2, %0\n\t"
-            "s_nop 1\n\t"
-            "s_and_b64 vcc, vcc, %3\n\t"
-            "s_cmp_eq_u64 vcc, %3\n\t"
-            "s_cbranch_scc1 Lr8_go_%=\n\t"
-            "s_sleep 1\n\t"
-            "s_branch Lr8_wait_%=\n"
-            "Lr8_go_%=:"
-            : "=&v"(v)
-            : "v"(ready_lane), "s"(steps), "s"(mask)
-            : "memory", "vcc", "scc");
-    };
-    auto signal_ready = [&](int slot, int steps) {
-        asm volatile("ds_write_b32 %0, %1" ::"v"(ready + slot * 4), "v"(steps) : "memory");
-    };
 
     // ---- prologue: everything is requested before anything is waited for (one memory round trip per launch; with the LDS-resident
     // fragments, the biases, the state and the first pre-activations fetched one group after the other it was eight).  The
@@ -843,7 +775,6 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     }
     for (int i = tid; i < 2 * NBH * 64; i += 64 * kR8Waves) ((uint4 *) smem)[i] = uint4{0, 0, 0, 0};
     if (tid < 4) ((int *) (smem + kR8Lds + 3 * 1024))[tid] = 0;
-    if (kFlags && tid < 32) ((int *) (smem + kR8Lds + 3 * 1024 + 16 + (kYHead ? kR8HeadLds : 0)))[tid] = 0;
     __syncthreads();
     // the operand's k = 271, 272 are the constant 1 against the two bias rows of the packed W_hh (kns_layout.h, kBiasK0): no bias
     // fetch and no accumulator splat in the step.  k = 271 (column 15 of tile 16) is rewritten by put_h16 every step, k = 272 is
@@ -911,9 +842,8 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
         const char *hc = (t & 1) ? hbuf1 : hbuf0;
         char *hn = (t & 1) ? hbuf0 : hbuf1;
         const frag_t *ha = (const frag_t *) hc;
-        if (!kFlags) publish(ha, hs_base);  // LDS holds h_{t-1}
+        publish(ha, hs_base);  // LDS holds h_{t-1}
         const __amdgpu_buffer_rsrc_t gnext = make_rsrc(gn_base, kGateTiles * 512);
-        const char *hs_slot = hs_base;
         hs_base += t > 0 ? hs_stride : 0;
         gn_base += t + 2 < g.T ? gi_stride : 0;
 
@@ -930,33 +860,23 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
             const f32x4 hnew = gate_block_bf16(pr, pz, pn, acc[0], acc[1], acc[2], hreg[q]);
             hreg[q] = hnew;
             put_h(hn, u, hnew);
-            if (kFlags) signal_ready(wave * 2 + q, t + 1);
         };
         // the chains start from the inline constant 0: b_hh rides in the operands (two rows of the packed W_hh against h's constant 1)
         auto acc_init = [&](f32x4 (&acc)[3], const int) {
 #pragma unroll
             for (int gt = 0; gt < 3; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
         };
-        // (kFlags) k-blocks 6 .. 8 of h_{t-1}: the second tiles of waves 4 .. 7 and tile 16
-        auto late = [&]() {
-            KNS_STAMP(11);
-            wait_ready(t, kAll);
-            KNS_STAMP(12);
-        };
-        constexpr int kGate0 = kFlags ? 6 : NBH;
-        if (kFlags) wait_ready(t, kEarly);
         KNS_STAMP(1);
         f32x4 acc[3];
         acc_init(acc, u0);
         if (kYHead && wave == 0) {  // ... with the head's chain on h_{t-1} (at t = 0: h_{-1}, into frame 0's slot, rewritten at t = 1)
             f32x4 ya = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (kFlags) r8_tile_mma<kR8RegFrags0, R8C_Q, kR8RegFrags0, true, 1, kApf, kGate0>(acc, ha, w0, wl0w, lane, &ya, wlh + lane, late); else r8_tile_mma<kR8RegFrags0, R8C_Q, kR8RegFrags0, true, 1, kApf>(acc, ha, w0, wl0w, lane, &ya, wlh + lane);
+            r8_tile_mma<kR8RegFrags0, R8C_Q, kR8RegFrags0, true, 1, kApf>(acc, ha, w0, wl0w, lane, &ya, wlh + lane);
             emit_y(ya, t > 0 ? t - 1 : 0);
         } else {
-            if constexpr (kFlags) r8_tile_mma<kR8RegFrags0, R8C_Q, kR8RegFrags0, false, 3, kApf, kGate0>(acc, ha, w0, wl0w, lane, nullptr, nullptr, late); else r8_tile_mma<kR8RegFrags0, R8C_Q, kR8RegFrags0, false, 3, kApf>(acc, ha, w0, wl0w, lane);
+            r8_tile_mma<kR8RegFrags0, R8C_Q, kR8RegFrags0, false, 3, kApf>(acc, ha, w0, wl0w, lane);
         }
         KNS_STAMP(2);
-        if (kFlags) publish(ha, hs_slot);  // every counter of step t - 1 has been seen: LDS holds all of h_{t-1}
         gates(0, acc);
         KNS_STAMP(3);
         acc_init(acc, u1);
@@ -988,16 +908,11 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
                 const float an = ((const float *) acc16)[(2 * 64 + lane) * 4 + e16];
                 h16 = gate_elem_bf16(xr, xz, xn, ar, az, an, h16);
                 put_h16(hn, h16);
-                if (kFlags) signal_ready(16 + e16, t + 1);
             }
         }
         KNS_STAMP(7);
-        if (!kFlags) __syncthreads();
-        KNS_STAMP(8);
-    }
-    if (kFlags) {  // all of h_{T-1}
-        wait_ready(g.T, kAll);
         __syncthreads();
+        KNS_STAMP(8);
     }
     if (kYHead && wave == 0) {  // the head of the last hidden vector
         const frag_t *hl = (const frag_t *) ((g.T & 1) ? hbuf1 : hbuf0);
@@ -1012,6 +927,9 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
     if (q16) g.hstate_out[(((size_t) mt * kUnitTiles + u2) * 64 + lane) * 4 + e16] = h16;
 }
 
+// (Round 6 measured a form WITHOUT the step's barrier -- per-tile step counters in LDS, the first MFMA loop waiting in front of k-blocks 0
+// and 6, which runs the two waves of a SIMD one window apart by construction: bit-identical, 171-175 us per launch against 155, MFMA / VALU
+// co-execution 16.7 % against 18.5 %; last commit that holds it: b283d69, record: profiles/r06_antiphase.txt.)
 // (Round 5 measured a form of the resident kernel that runs TWO m-tiles per workgroup -- the consumer half of a producer/consumer CU
 // pair -- as a timing variant, gru_r8x2_kernel: 4 113-4 492 ticks per m-tile-step against 4 714, on half the chip; not adopted.  The
 // source left the tree with the experiment: last commit that holds it is a6273b0; record: profiles/r05_r8x2_consumer.txt.  Likewise the
@@ -1019,15 +937,10 @@ __global__ __launch_bounds__(64 * kR8Waves, 2) void gru_resident8_kernel(GruArgs
 // profiles/r05_gate_lut.txt).)
 void launch_gru(const GruArgs &a, hipStream_t s) {
     const bool stream_weights = (a.dev & kDevGruStream) != 0;  // A/B switch (developer build only)
-    const bool barrier = (a.dev & kDevGruBarrier) != 0 || !R8_FLAGS;  // A/B switch: round 1-5's form, one barrier per step
-    if (a.precision == kBf16 && !stream_weights && a.yw && barrier)
-        hipLaunchKernelGGL((gru_resident8_kernel<true, false>), dim3(a.mtiles), dim3(64 * kR8Waves), 0, s, a);
-    else if (a.precision == kBf16 && !stream_weights && barrier)
-        hipLaunchKernelGGL((gru_resident8_kernel<false, false>), dim3(a.mtiles), dim3(64 * kR8Waves), 0, s, a);
-    else if (a.precision == kBf16 && !stream_weights && a.yw)
-        hipLaunchKernelGGL((gru_resident8_kernel<true, true>), dim3(a.mtiles), dim3(64 * kR8Waves), 0, s, a);
+    if (a.precision == kBf16 && !stream_weights && a.yw)
+        hipLaunchKernelGGL(gru_resident8_kernel<true>, dim3(a.mtiles), dim3(64 * kR8Waves), 0, s, a);
     else if (a.precision == kBf16 && !stream_weights)
-        hipLaunchKernelGGL((gru_resident8_kernel<false, true>), dim3(a.mtiles), dim3(64 * kR8Waves), 0, s, a);
+        hipLaunchKernelGGL(gru_resident8_kernel<false>, dim3(a.mtiles), dim3(64 * kR8Waves), 0, s, a);
     else if (a.precision == kBf16)
         hipLaunchKernelGGL((gru_kernel<PBF16, 8>), dim3(a.mtiles), dim3(512), 0, s, a);
     else

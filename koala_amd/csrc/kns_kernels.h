@@ -31,7 +31,7 @@ inline const char *dev_env(const char *name) { return getenv(name); }
 inline const char *dev_env(const char *) { return nullptr; }
 #endif
 // kernel-family overrides carried in the launch arguments (set by the engine from its developer switches; 0 in the product)
-enum DevVariant { kDevGruStream = 1, kDevGemmGeneric = 2, kDevGemmNoWsr = 4, kDevGruBarrier = 8 };
+enum DevVariant { kDevGruStream = 1, kDevGemmGeneric = 2, kDevGemmNoWsr = 4 };
 
 // ---- analysis: int16 frames -> spectrum + normalised log-power features (SURVEY 8a rows a2+a3)
 struct AnalysisArgs {

@@ -416,11 +416,10 @@ def test_alternative_kernels_give_identical_pcm(random_model, random5_model):
     digests['product'] = [ln for ln in out.stdout.splitlines() if ln.startswith('DIGEST')][-1]
     script = _SWITCH_SCRIPT % {'root': root, 'tests': os.path.join(root, 'tests'), 'model': random_model, 'model5': random5_model,
                                'lib': DEV_LIB}
-    for switch in ('', 'KOALA_AMD_GRU_STREAM', 'KOALA_AMD_GRU_BARRIER', 'KOALA_AMD_GEMM_GENERIC',
+    for switch in ('', 'KOALA_AMD_GRU_STREAM', 'KOALA_AMD_GEMM_GENERIC',
                    'KOALA_AMD_GEMM_NO_WSR', 'KOALA_AMD_NO_SMALL', 'KOALA_AMD_NO_GRAPH', 'KOALA_AMD_STORE_SPECTRUM',
                    'KOALA_AMD_DEBUG_TAPS', 'KOALA_AMD_NO_QUAD', 'KOALA_AMD_NO_HEAD_FUSE', 'KOALA_AMD_NO_STFT_FUSE', 'KOALA_AMD_WAVE_MT=0',
-                   'KOALA_AMD_WAVE_MT=4096', 'KOALA_AMD_WAVE_GROUP=2', 'KOALA_AMD_NO_SPIN_WAIT'):  # (KOALA_AMD_GRU_BARRIER: the resident recurrent kernel
-        # with one barrier per step -- rounds 1-5 -- instead of per-tile step counters; KOALA_AMD_NO_QUAD: one-frame calls of large
+                   'KOALA_AMD_WAVE_MT=4096', 'KOALA_AMD_WAVE_GROUP=2', 'KOALA_AMD_NO_SPIN_WAIT'):  # (KOALA_AMD_NO_QUAD: one-frame calls of large
         # batches through input GEMM + recurrent kernel instead of the one-step quad kernel, kns_gruq.hip; KOALA_AMD_WAVE_MT: multi-frame
         # calls never / always as a wavefront over (layer, frame), kns_gru.hip gru_wave_kernel; _GROUP: its m-tiles per workgroup;
         # KOALA_AMD_NO_SPIN_WAIT: one-frame host calls wait in hipStreamSynchronize instead of spinning on the frame's completion word)
