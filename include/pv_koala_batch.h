@@ -74,7 +74,9 @@ PV_API pv_status_t pv_koala_batch_delay_sample(const pv_koala_batch_t *object, i
 PV_API pv_status_t pv_koala_batch_host_alloc(int64_t num_bytes, void **memory);
 PV_API void pv_koala_batch_host_free(void *memory);
 
-/* Run on a caller-provided HIP stream (a hipStream_t passed as void*; NULL = the handle's own stream). */
+/* Run on a caller-provided HIP stream (a hipStream_t passed as void*; NULL = the handle's own stream).  Changing the stream first
+ * waits for everything the handle has in flight (asynchronous host calls, work queued on the previous stream -- which must still
+ * exist), since the next call's kernels work on the same stream state. */
 PV_API pv_status_t pv_koala_batch_set_stream(pv_koala_batch_t *object, void *hip_stream);
 /* Blocks until everything enqueued by this handle -- device-pointer calls, asynchronous host calls -- has finished. */
 PV_API pv_status_t pv_koala_batch_synchronize(pv_koala_batch_t *object);

@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -242,6 +243,58 @@ std::string gpu_name(int device) {
 
 // ------------------------------------------------------------------------------------------------ engine
 
+struct Engine::WeightImage {
+    int device = 0;
+    size_t bytes = 0;
+    std::vector<void *> allocs;
+    float *window = nullptr, *twiddle = nullptr, *mean = nullptr, *scale = nullptr, *b_in = nullptr;
+    void *w_in = nullptr;
+    StageDev sd[kStages]{};
+    int nby[kStages] = {0, 0, 0, 0};
+    ~WeightImage() {
+        (void) hipSetDevice(device);
+        for (void *p : allocs) (void) hipFree(p);
+    }
+};
+
+namespace {
+// content key of a parameter set: 64-bit multiply-xor over every tensor (15 MB: ~2 ms), plus the dimensions
+uint64_t params_key(const Params &p) {
+    uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t) p.front_taps;
+    auto mix = [&](const std::vector<float> &v) {
+        const size_t n = v.size();
+        h = (h ^ n) * 0xff51afd7ed558ccdull;
+        const uint32_t *u = (const uint32_t *) v.data();
+        size_t i = 0;
+        for (; i + 1 < n; i += 2) {
+            const uint64_t w = (uint64_t) u[i] | ((uint64_t) u[i + 1] << 32);
+            h = (h ^ w) * 0x9e3779b97f4a7c15ull;
+            h ^= h >> 29;
+        }
+        if (i < n) h = (h ^ u[i]) * 0x9e3779b97f4a7c15ull;
+    };
+    mix(p.mean), mix(p.scale), mix(p.w_in), mix(p.b_in);
+    for (int s = 0; s < kStages; ++s) {
+        const Params::Stage &st = p.st[s];
+        h = (h ^ (uint64_t) (st.d_in * 1024 + st.d_out)) * 0xff51afd7ed558ccdull;
+        mix(st.w_ih_a), mix(st.b_ih_a), mix(st.w_hh_a), mix(st.b_hh_a), mix(st.w_ih_b), mix(st.b_ih_b), mix(st.w_hh_b), mix(st.b_hh_b),
+            mix(st.w_head), mix(st.b_head);
+    }
+    return h;
+}
+struct ImageKey {
+    uint64_t content;
+    int device, precision;
+    bool operator<(const ImageKey &o) const {
+        return content != o.content ? content < o.content : device != o.device ? device < o.device : precision < o.precision;
+    }
+};
+std::mutex g_image_mutex;
+std::map<ImageKey, std::weak_ptr<void>> g_images;  // (weak: an image lives as long as a handle holds it)
+}  // namespace
+
+size_t Engine::shared_device_bytes() const { return weights_ ? weights_->bytes : 0; }
+
 void *Engine::dalloc(size_t bytes, bool zero) {
     void *p = nullptr;
     if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) {
@@ -249,7 +302,13 @@ void *Engine::dalloc(size_t bytes, bool zero) {
         alloc_failed_ = true;
         return nullptr;
     }
-    allocs_.push_back(p);
+    if (alloc_sink_) {
+        alloc_sink_->push_back(p);
+        weights_->bytes += bytes ? bytes : 16;
+    } else {
+        allocs_.push_back(p);
+        own_bytes_ += bytes ? bytes : 16;
+    }
     // (on the handle's own non-blocking stream: a legacy-stream operation would collide with another handle's graph capture)
     if (zero) (void) hipMemsetAsync(p, 0, bytes, own_stream_);
     return p;
@@ -280,94 +339,9 @@ Engine *Engine::create(const Params &p, int device, int num_streams, int max_fra
     return e.release();
 }
 
-bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, std::string *err, bool *oom) {
-    if (hipSetDevice(device) != hipSuccess) {
-        (void) hipGetLastError();
-        *err = "Failed to communicate with device.";
-        return false;
-    }
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
-        (void) hipGetLastError();
-        *err = "Failed to communicate with device.";
-        return false;
-    }
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        *err = std::string("GPU `") + prop.gcnArchName + "` is not supported: this build carries gfx950 (MI355X) code only.";
-        return false;
-    }
-    device_ = device;
-    B_ = B;
-    Bpad_ = ceil_div(B, 16) * 16;
-    Tmax_ = Tmax;
-    prec_ = precision;
-    pi_ = prec_info(precision);
-    nbf_ = ceil_div(kBins, pi_.kb);
-    nbh_ = ceil_div(kHidden, pi_.kb);
-    taps_ = p.front_taps;
-    fold_ = precision == kBf16 && taps_ == 1;  // the front-end rides in the stage-input GEMMs (see the packing below)
-    if (hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking) != hipSuccess) {
-        (void) hipGetLastError();
-        *err = "Failed to create a HIP stream.";
-        return false;
-    }
-    stream_ = own_stream_;
-    // developer switches: read once per handle, and only in the -DKNS_DEV build (dev_env() is a constant nullptr otherwise)
-    use_graph_ = dev_env("KOALA_AMD_NO_GRAPH") == nullptr;
-    no_small_ = dev_env("KOALA_AMD_NO_SMALL") != nullptr;
-    no_zero_copy_ = dev_env("KOALA_AMD_NO_ZERO_COPY") != nullptr;
-    no_recompute_ = dev_env("KOALA_AMD_STORE_SPECTRUM") != nullptr;  // A/B switch: spectrum through HBM in every call
-    debug_taps_ = dev_env("KOALA_AMD_DEBUG_TAPS") != nullptr;        // keep every intermediate debug_read() can return
-    dev_variant_ = (dev_env("KOALA_AMD_GRU_STREAM") ? kDevGruStream : 0) | (dev_env("KOALA_AMD_GEMM_GENERIC") ? kDevGemmGeneric : 0) |
-                   (dev_env("KOALA_AMD_GEMM_NO_WSR") ? kDevGemmNoWsr : 0);
-    auto dev_int = [](const char *name, int dflt) {
-        const char *e = dev_env(name);
-        return e ? atoi(e) : dflt;
-    };
-    dev_only_class_ = dev_int("KOALA_AMD_ONLY_CLASS", -1);  // power / clock probing: launch one kernel class only (garbage out)
-    dev_analysis_seg_ = dev_int("KOALA_AMD_ANALYSIS_SEG", 0);
-    dev_synth_seg_ = dev_int("KOALA_AMD_SYNTH_SEG", 0);
-    dev_small_mt_ = dev_int("KOALA_AMD_SMALL_MT", 0);
-    dev_steps_mt_ = dev_int("KOALA_AMD_STEPS_MT", 192);
-    dev_wave_mt_ = dev_int("KOALA_AMD_WAVE_MT", -1);  // -1: the measured limits; 0: never
-    dev_wave_group_ = dev_int("KOALA_AMD_WAVE_GROUP", 0);
-    dev_wave_parts_ = dev_int("KOALA_AMD_WAVE_PARTS", 1);  // 0: a layer never takes more than one XCD
-    // One-frame calls of large batches: a GRU layer as ONE launch fused over CU quads (kns_gruq.hip, gru_quad1_kernel), bit-identical
-    // to the two-kernel form -- a CU pulls a quarter of W_ih and W_hh (300 KiB) per layer instead of a half of one and all of the
-    // other (~740 KiB): 128 against 222 us per 4096-stream frame step.  (The multi-frame form of that decomposition measured slower
-    // than input GEMM + recurrent kernel, 354 against 278 us per layer at 64 frames, and is no longer in the tree: DESIGN.md section 6.)
-    use_quad_ = dev_env("KOALA_AMD_NO_QUAD") == nullptr;
-    fuse_head_ = dev_env("KOALA_AMD_NO_HEAD_FUSE") == nullptr;
-    fuse_front_ = dev_env("KOALA_AMD_NO_STFT_FUSE") == nullptr;  // A/B arm: front-end / mask head as launches of their own in one-frame calls  // A/B arm: narrow heads as launches of their own in one-frame calls
-    quad_nb0_max_ = dev_int("KOALA_AMD_QUAD_NB0MAX", 2);
-    qdbg_block_ = dev_int("KOALA_AMD_QUAD_DBG", -1);
-    // host-pointer calls are cut into sub-chunks of host_chunk_ frames (two staging slots = the Tmax-sized buffers)
-    host_chunk_ = Tmax_ / 2 < 1 ? 1 : (Tmax_ / 2 > 16 ? 16 : Tmax_ / 2);
-    host_pipeline_min_bytes_ = (size_t) 4 << 20;  // below this a call is launch-bound: sub-chunks would only add launches
-    if (const char *e = dev_env("KOALA_AMD_HOST_SCHED")) {  // sub-chunk lengths "6,8,12,...": repeated / truncated to the call's frames
-        for (const char *q = e; *q;) {
-            dev_host_sched_.push_back(atoi(q));
-            while (*q && *q != ',') ++q;
-            if (*q == ',') ++q;
-        }
-    }
-    if (const char *e = dev_env("KOALA_AMD_HOST_CHUNK")) {  // force a sub-chunk length; 0 = never split
-        const int v = atoi(e);
-        if (v >= 1 && v <= Tmax_ / 2) host_chunk_ = v, host_pipeline_min_bytes_ = 0;
-        if (v == 0) host_chunk_ = Tmax_;
-    }
-    bool ok_sync = hipStreamCreateWithFlags(&copy_in_, hipStreamNonBlocking) == hipSuccess &&
-                   hipStreamCreateWithFlags(&copy_out_, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; i < 2 && ok_sync; ++i)
-        ok_sync = hipEventCreateWithFlags(&ev_in_[i], hipEventDisableTiming) == hipSuccess &&
-                  hipEventCreateWithFlags(&ev_done_[i], hipEventDisableTiming) == hipSuccess &&
-                  hipEventCreateWithFlags(&ev_out_[i], hipEventDisableTiming) == hipSuccess;
-    if (!ok_sync) {
-        (void) hipGetLastError();
-        *err = "Failed to create HIP streams/events.";
-        return false;
-    }
-
+// Tables and packed weights of one (model, device, precision): runs once per image, under g_image_mutex, with dalloc() recording into
+// the image (alloc_sink_); leaves the pointers in this handle's members, from where init() copies them into the image.
+bool Engine::build_weights(const Params &p, int precision, std::string *err) {
     // ---- tables
     std::vector<float> win(kNfft), tw(2 * kNfft);
     const double pi = 3.14159265358979323846;
@@ -499,6 +473,130 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
         *err = "Internal error: a packed weight image has non-zero padding rows.";
         return false;
     }
+    return true;
+
+}
+
+bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, std::string *err, bool *oom) {
+    if (hipSetDevice(device) != hipSuccess) {
+        (void) hipGetLastError();
+        *err = "Failed to communicate with device.";
+        return false;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        (void) hipGetLastError();
+        *err = "Failed to communicate with device.";
+        return false;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        *err = std::string("GPU `") + prop.gcnArchName + "` is not supported: this build carries gfx950 (MI355X) code only.";
+        return false;
+    }
+    device_ = device;
+    B_ = B;
+    Bpad_ = ceil_div(B, 16) * 16;
+    Tmax_ = Tmax;
+    prec_ = precision;
+    pi_ = prec_info(precision);
+    nbf_ = ceil_div(kBins, pi_.kb);
+    nbh_ = ceil_div(kHidden, pi_.kb);
+    taps_ = p.front_taps;
+    fold_ = precision == kBf16 && taps_ == 1;  // the front-end rides in the stage-input GEMMs (see the packing below)
+    if (hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking) != hipSuccess) {
+        (void) hipGetLastError();
+        *err = "Failed to create a HIP stream.";
+        return false;
+    }
+    stream_ = own_stream_;
+    // developer switches: read once per handle, and only in the -DKNS_DEV build (dev_env() is a constant nullptr otherwise)
+    use_graph_ = dev_env("KOALA_AMD_NO_GRAPH") == nullptr;
+    no_small_ = dev_env("KOALA_AMD_NO_SMALL") != nullptr;
+    no_zero_copy_ = dev_env("KOALA_AMD_NO_ZERO_COPY") != nullptr;
+    no_recompute_ = dev_env("KOALA_AMD_STORE_SPECTRUM") != nullptr;  // A/B switch: spectrum through HBM in every call
+    debug_taps_ = dev_env("KOALA_AMD_DEBUG_TAPS") != nullptr;        // keep every intermediate debug_read() can return
+    dev_variant_ = (dev_env("KOALA_AMD_GRU_STREAM") ? kDevGruStream : 0) | (dev_env("KOALA_AMD_GEMM_GENERIC") ? kDevGemmGeneric : 0) |
+                   (dev_env("KOALA_AMD_GEMM_NO_WSR") ? kDevGemmNoWsr : 0);
+    auto dev_int = [](const char *name, int dflt) {
+        const char *e = dev_env(name);
+        return e ? atoi(e) : dflt;
+    };
+    dev_only_class_ = dev_int("KOALA_AMD_ONLY_CLASS", -1);  // power / clock probing: launch one kernel class only (garbage out)
+    dev_analysis_seg_ = dev_int("KOALA_AMD_ANALYSIS_SEG", 0);
+    dev_synth_seg_ = dev_int("KOALA_AMD_SYNTH_SEG", 0);
+    dev_small_mt_ = dev_int("KOALA_AMD_SMALL_MT", 0);
+    dev_steps_mt_ = dev_int("KOALA_AMD_STEPS_MT", 192);
+    dev_wave_mt_ = dev_int("KOALA_AMD_WAVE_MT", -1);  // -1: the measured limits; 0: never
+    dev_wave_group_ = dev_int("KOALA_AMD_WAVE_GROUP", 0);
+    dev_wave_parts_ = dev_int("KOALA_AMD_WAVE_PARTS", 1);  // 0: a layer never takes more than one XCD
+    // One-frame calls of large batches: a GRU layer as ONE launch fused over CU quads (kns_gruq.hip, gru_quad1_kernel), bit-identical
+    // to the two-kernel form -- a CU pulls a quarter of W_ih and W_hh (300 KiB) per layer instead of a half of one and all of the
+    // other (~740 KiB): 128 against 222 us per 4096-stream frame step.  (The multi-frame form of that decomposition measured slower
+    // than input GEMM + recurrent kernel, 354 against 278 us per layer at 64 frames, and is no longer in the tree: DESIGN.md section 6.)
+    use_quad_ = dev_env("KOALA_AMD_NO_QUAD") == nullptr;
+    fuse_head_ = dev_env("KOALA_AMD_NO_HEAD_FUSE") == nullptr;
+    fuse_front_ = dev_env("KOALA_AMD_NO_STFT_FUSE") == nullptr;  // A/B arm: front-end / mask head as launches of their own in one-frame calls  // A/B arm: narrow heads as launches of their own in one-frame calls
+    quad_nb0_max_ = dev_int("KOALA_AMD_QUAD_NB0MAX", 2);
+    qdbg_block_ = dev_int("KOALA_AMD_QUAD_DBG", -1);
+    // host-pointer calls are cut into sub-chunks of host_chunk_ frames (two staging slots = the Tmax-sized buffers)
+    host_chunk_ = Tmax_ / 2 < 1 ? 1 : (Tmax_ / 2 > 16 ? 16 : Tmax_ / 2);
+    host_pipeline_min_bytes_ = (size_t) 4 << 20;  // below this a call is launch-bound: sub-chunks would only add launches
+    if (const char *e = dev_env("KOALA_AMD_HOST_SCHED")) {  // sub-chunk lengths "6,8,12,...": repeated / truncated to the call's frames
+        for (const char *q = e; *q;) {
+            dev_host_sched_.push_back(atoi(q));
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+    }
+    if (const char *e = dev_env("KOALA_AMD_HOST_CHUNK")) {  // force a sub-chunk length; 0 = never split
+        const int v = atoi(e);
+        if (v >= 1 && v <= Tmax_ / 2) host_chunk_ = v, host_pipeline_min_bytes_ = 0;
+        if (v == 0) host_chunk_ = Tmax_;
+    }
+    bool ok_sync = hipStreamCreateWithFlags(&copy_in_, hipStreamNonBlocking) == hipSuccess &&
+                   hipStreamCreateWithFlags(&copy_out_, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2 && ok_sync; ++i)
+        ok_sync = hipEventCreateWithFlags(&ev_in_[i], hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&ev_done_[i], hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&ev_out_[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok_sync) {
+        (void) hipGetLastError();
+        *err = "Failed to create HIP streams/events.";
+        return false;
+    }
+
+    // ---- tables and weights: shared with every other handle open on the same model, device and precision
+    {
+        std::lock_guard<std::mutex> lock(g_image_mutex);
+        const ImageKey key{params_key(p), device, precision};
+        std::shared_ptr<void> held = g_images[key].lock();
+        // (KOALA_AMD_NO_WEIGHT_CACHE, developer build: every handle builds its own image, as in rounds 1-5)
+        if (held && !dev_env("KOALA_AMD_NO_WEIGHT_CACHE")) {
+            weights_ = std::static_pointer_cast<WeightImage>(held);
+            weights_cached_ = true;
+        } else {
+            weights_ = std::make_shared<WeightImage>();
+            weights_->device = device;
+            alloc_sink_ = &weights_->allocs;
+            const bool built = build_weights(p, precision, err);
+            alloc_sink_ = nullptr;
+            if (!built) return false;
+            if (alloc_failed_) {
+                *oom = true;
+                *err = "Failed to allocate device memory.";
+                return false;
+            }
+            WeightImage &w = *weights_;
+            w.window = d_window_, w.twiddle = d_twiddle_, w.mean = d_mean_, w.scale = d_scale_, w.w_in = w_in_, w.b_in = b_in_;
+            for (int s = 0; s < kStages; ++s) w.sd[s] = sd_[s], w.nby[s] = nby_[s];
+            for (auto it = g_images.begin(); it != g_images.end();)  // (entries whose last handle is gone)
+                it = it->second.expired() ? g_images.erase(it) : std::next(it);
+            g_images[key] = std::static_pointer_cast<void>(weights_);
+        }
+        const WeightImage &w = *weights_;
+        d_window_ = w.window, d_twiddle_ = w.twiddle, d_mean_ = w.mean, d_scale_ = w.scale, w_in_ = w.w_in, b_in_ = w.b_in;
+        for (int s = 0; s < kStages; ++s) sd_[s] = w.sd[s], nby_[s] = w.nby[s];
+    }
 
     // ---- per-stream state
     const size_t mtb = (size_t) Bpad_ / 16;
@@ -554,7 +652,12 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     } else {
         *h_frame_word_ = 0;
     }
-    spin_wait_ = dev_env("KOALA_AMD_NO_SPIN_WAIT") == nullptr;
+    // KOALA_AMD_WAIT=block (product option): one-frame host calls sleep in hipStreamSynchronize instead of polling the frame's
+    // completion word -- for hosts that run more streaming handles than they have cores
+    {
+        const char *w = getenv("KOALA_AMD_WAIT");
+        spin_wait_ = dev_env("KOALA_AMD_NO_SPIN_WAIT") == nullptr && !(w && !strcmp(w, "block"));
+    }
     if (taps_ > 1) {  // the front-end context of a fresh stream is silence, not zeros
         AnalysisArgs an;
         an.pcm = d_in_;  // zeros (at least one frame of B_ >= 1 streams; rows past the last stream re-read the last one)
@@ -1305,6 +1408,16 @@ bool Engine::process_host_pipelined(int T, const int16_t *pcm, int16_t *out, boo
     return true;
 }
 
+void Engine::set_stream(hipStream_t s) {
+    hipStream_t next = s ? s : own_stream_;
+    if (next == stream_) return;
+    (void) hipSetDevice(device_);
+    std::string ignored;
+    (void) drain_async(&ignored);
+    if (hipStreamSynchronize(stream_) != hipSuccess) (void) hipGetLastError();
+    stream_ = next;
+}
+
 bool Engine::drain_async(std::string *err) {
     bool ok = true;
     for (int i = 0; i < 4; ++i) {
@@ -1355,22 +1468,23 @@ bool Engine::process_host_async(int T, const int16_t *pcm, int16_t *out, std::st
             return false;
         }
     }
-    if (!aev_out_[0]) {
+    if (!async_ready_) {  // set only once EVERY event and both buffers exist: a partial failure is retried by the next call
         bool ok = true;
-        for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreateWithFlags(&aev_out_[i], hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; i < 2 && ok; ++i)
-            ok = hipEventCreateWithFlags(&aev_in_[i], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&aev_done_[i], hipEventDisableTiming) == hipSuccess;
-        if (ok) {
-            d_in2_ = (int16_t *) dalloc((size_t) B_ * Tmax_ * kFrame * 2, false);
-            d_out2_ = (int16_t *) dalloc((size_t) B_ * Tmax_ * kFrame * 2, false);
-            ok = d_in2_ && d_out2_;
+        for (int i = 0; i < 4 && ok; ++i)
+            if (!aev_out_[i]) ok = hipEventCreateWithFlags(&aev_out_[i], hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 2 && ok; ++i) {
+            if (!aev_in_[i]) ok = hipEventCreateWithFlags(&aev_in_[i], hipEventDisableTiming) == hipSuccess;
+            if (ok && !aev_done_[i]) ok = hipEventCreateWithFlags(&aev_done_[i], hipEventDisableTiming) == hipSuccess;
         }
+        if (ok && !d_in2_) d_in2_ = (int16_t *) dalloc((size_t) B_ * Tmax_ * kFrame * 2, false);
+        if (ok && !d_out2_) d_out2_ = (int16_t *) dalloc((size_t) B_ * Tmax_ * kFrame * 2, false);
+        ok = ok && d_in2_ && d_out2_;
         if (!ok) {
             (void) hipGetLastError();
             *err = "Failed to allocate the second staging slot of asynchronous host calls.";
             return false;
         }
+        async_ready_ = true;
     }
     const unsigned n = async_n_;
     const int s = (int) (n & 1u), ring = (int) (n & 3u), ring3 = (int) ((n - 3u) & 3u), ring2 = (int) ((n - 2u) & 3u);
@@ -1390,9 +1504,13 @@ bool Engine::process_host_async(int T, const int16_t *pcm, int16_t *out, std::st
     if (n >= 2) ok = ok && hipStreamWaitEvent(stream_, aev_out_[ring2], 0) == hipSuccess;  // ... and its copy-out this slot's output
     if (!ok) {
         *err = std::string("HIP error: ") + hipGetErrorString(hipGetLastError());
+        (void) hipDeviceSynchronize();  // (a copy-in may have been enqueued: nothing of this call stays in flight)
         return false;
     }
-    if (!run_device(T, din, dout, err)) return false;
+    if (!run_device(T, din, dout, err)) {
+        (void) hipDeviceSynchronize();
+        return false;
+    }
     ok = hipEventRecord(aev_done_[s], stream_) == hipSuccess;
     ok = ok && hipStreamWaitEvent(copy_out_, aev_done_[s], 0) == hipSuccess;
     // (as a 2-D copy of B_ rows: the runtime hands those to the copy engines; a plain hipMemcpyAsync into page-locked memory went
@@ -1477,19 +1595,33 @@ bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err, 
             if (hipGraphLaunch(frame_graph_[parity], stream_) != hipSuccess) goto fail;
             hs_cur_ = hs ^ 1;
             if (frame_graph_signals_[parity]) {
-                // Spin on the frame's completion word (a frame takes 60-100 us: longer than the runtime's own active-wait window,
+                // Poll the frame's completion word (a frame takes 50-100 us: longer than the runtime's own active-wait window,
                 // after which hipStreamSynchronize sleeps on an interrupt and wakes up whenever the host scheduler gets to it).
-                // Bounded: a frame that has not reported after 20 ms is handed to hipStreamSynchronize, which also surfaces errors.
+                // The first ~250 us -- two to five frame times -- in a tight loop, then yielding the core between polls (a host that
+                // runs more handles than cores must not have its pollers starve each other); a frame that has not reported
+                // after 20 ms is handed to hipStreamSynchronize, which also surfaces errors.
                 const unsigned want = ++frame_seq_;
                 const auto t0 = std::chrono::steady_clock::now();
-                bool seen = false;
+                bool seen = false, yielding = false;
                 for (unsigned spins = 0;; ++spins) {
                     if (__atomic_load_n(h_frame_word_, __ATOMIC_ACQUIRE) == want) {
                         seen = true;
                         break;
                     }
-                    __builtin_ia32_pause();
-                    if ((spins & 0x3ff) == 0x3ff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+                    if (yielding) {
+                        std::this_thread::yield();
+                    } else {
+#if defined(__x86_64__) || defined(__i386__)
+                        __builtin_ia32_pause();
+#elif defined(__aarch64__)
+                        asm volatile("yield" ::: "memory");
+#endif
+                    }
+                    if (yielding || (spins & 0xff) == 0xff) {
+                        const auto dt = std::chrono::steady_clock::now() - t0;
+                        if (dt > std::chrono::milliseconds(20)) break;
+                        yielding = dt > std::chrono::microseconds(250);
+                    }
                 }
                 if (!seen) {
                     if (hipStreamSynchronize(stream_) != hipSuccess) goto fail;

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -37,6 +38,11 @@ public:
                           std::string *err, bool *oom);
     ~Engine();
 
+    // bytes of device memory this handle allocated itself / bytes of the weight image it shares (first handle on a model: it built it)
+    size_t own_device_bytes() const { return own_bytes_; }
+    size_t shared_device_bytes() const;
+    bool weights_were_cached() const { return weights_cached_; }
+
     int num_streams() const { return B_; }
     int max_frames() const { return Tmax_; }
     int device() const { return device_; }
@@ -51,7 +57,9 @@ public:
     bool drain_async(std::string *err);
     bool async_wait(int max_in_flight, std::string *err);  // until at most that many asynchronous calls are still in flight (0: all done)
     bool reset(const uint8_t *host_mask, std::string *err);
-    void set_stream(hipStream_t s) { stream_ = s ? s : own_stream_; }
+    // 0: back to the handle's own stream.  Waits for everything the handle has in flight first (asynchronous host calls and the work
+    // queued on the previous stream, which must still exist: the next call's kernels touch the same state, history and tail buffers)
+    void set_stream(hipStream_t s);
     bool synchronize(std::string *err);
 
     void profile_enable(bool on);
@@ -67,11 +75,21 @@ private:
     void tick(int cls);
     void tock(int cls);
 
+    // The immutable part of a handle -- tables and every packed weight matrix -- is built once per (model content, device, precision,
+    // developer switches) and SHARED by all handles that are open on it (round 6: the reference's contract is one handle per stream,
+    // include/pv_koala.h:26-63; a caller with N handles used to get N folds, N packings and N weight images).  Ref-counted: freed with the
+    // last handle.  A handle copies the image's pointers into its own members below; only its allocations differ.
+    struct WeightImage;
+    std::shared_ptr<WeightImage> weights_;
+    std::vector<void *> *alloc_sink_ = nullptr;  // while an image is being built: where dalloc() records its allocations
+    bool build_weights(const Params &p, int precision, std::string *err);
+
     int device_ = 0, B_ = 0, Bpad_ = 0, Tmax_ = 0, prec_ = 0, last_T_ = 0;
     PrecInfo pi_{};
     int nbf_ = 0, nbh_ = 0, nby_[kStages] = {0, 0, 0, 0};
     hipStream_t own_stream_ = nullptr, stream_ = nullptr;
-    bool alloc_failed_ = false;
+    bool alloc_failed_ = false, weights_cached_ = false;
+    size_t own_bytes_ = 0;
     std::vector<void *> allocs_;
 
     // parameters on device
@@ -118,6 +136,7 @@ private:
     void run_wave(int T, int mtb);
     // asynchronous host calls: two slots of full-size device staging (slot 0 = d_in_ / d_out_, slot 1 allocated on first use)
     int16_t *d_in2_ = nullptr, *d_out2_ = nullptr;
+    bool async_ready_ = false;  // every event and both staging slots of the asynchronous host path exist
     hipEvent_t aev_in_[2] = {nullptr, nullptr}, aev_done_[2] = {nullptr, nullptr}, aev_out_[4] = {nullptr, nullptr, nullptr, nullptr};
     bool async_busy_[4] = {false, false, false, false};  // by call number mod 4: the window is three calls
     unsigned async_n_ = 0;

@@ -99,7 +99,8 @@ def test_product_library_reads_no_developer_switch(native_library):
                  b'KOALA_AMD_DEBUG_TAPS', b'KOALA_AMD_HOST_CHUNK', b'KOALA_AMD_HOST_SCHED', b'KOALA_AMD_NO_SPIN_WAIT'):
         assert name not in blob, name
         assert name in dev, name
-    assert b'KOALA_AMD_PRECISION' in blob  # the one documented run-time option of the single-stream ABI
+    assert b'KOALA_AMD_PRECISION' in blob  # the documented run-time options of the single-stream ABI: precision ...
+    assert b'KOALA_AMD_WAIT' in blob       # ... and how a one-frame call waits for its frame (poll / block)
 
 
 def test_constants(lib, fx):

@@ -825,3 +825,59 @@ def test_baseline_config2_b4096_t64_bf16_at_its_exact_shape(random_model):
         assert (d <= 1).mean() >= 0.999, (c, float((d <= 1).mean()))
         assert np.array_equal(y.reshape(B // distinct, distinct, -1), np.broadcast_to(y[:distinct], (B // distinct, distinct, y.shape[1])))
     kb.delete()
+
+
+def test_many_single_stream_handles_share_one_weight_image(random_model, gate_model):
+    """The reference's contract is one handle per stream (include/pv_koala.h:26-63): 64 pv_koala_init handles alive at once, driven from
+    four threads, each on its own signal -- every frame of every handle is the fp32 oracle's; the handles share ONE device image of the
+    packed weights per (model, precision) (kns_engine.cpp, WeightImage), so the 2nd .. 64th cost their state and workspace only; a
+    handle on another model or precision gets its own image; and the image goes when its last handle does."""
+    import threading
+    torch = pytest.importorskip('torch')
+    nh, frames = 64, 12
+    x = synth_streams(nh, frames, seed=64)
+    want = run_oracle(random_model, x)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    first = koala_amd.create('key', model_path=random_model, device='gpu:0')
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    handles = [first] + [koala_amd.create('key', model_path=random_model, device='gpu:0') for _ in range(nh - 1)]
+    torch.cuda.synchronize()
+    free2 = torch.cuda.mem_get_info()[0]
+    per_later = (free1 - free2) / float(nh - 1)
+    print('first handle %.1f MiB, each of the next %d: %.2f MiB' % ((free0 - free1) / 2.0 ** 20, nh - 1, per_later / 2.0 ** 20))
+    # the fp32 weight image alone is 29 MB: a later handle must cost far less than that (allocation granularity included)
+    assert per_later < 8 << 20, per_later
+    other = koala_amd.create('key', model_path=gate_model, device='gpu:0')  # another model: its own image, its own results
+    outs, errors = [None] * nh, []
+
+    def worker(lo, hi):
+        try:
+            for f in range(frames):
+                for i in range(lo, hi):
+                    y = np.array(handles[i].process(x[i, f * 256:(f + 1) * 256]), np.int16)
+                    outs[i] = y if f == 0 else np.concatenate([outs[i], y])
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+    threads = [threading.Thread(target=worker, args=(q * nh // 4, (q + 1) * nh // 4)) for q in range(4)]
+    for t in threads:
+        t.start()
+    o = np.concatenate([np.array(other.process(x[0, f * 256:(f + 1) * 256]), np.int16) for f in range(frames)])
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(nh):
+        assert np.array_equal(outs[i], want[i]), i
+    assert np.array_equal(o, run_oracle(gate_model, x[:1])[0])
+    for h in handles[:-1]:
+        h.delete()
+    # the last handle still works after 63 others released the image
+    last = np.array(handles[-1].process(x[nh - 1, :256]), np.int16)
+    ref = oracle.Oracle(random_model, 1)
+    ref.process(x[nh - 1:nh])
+    assert np.array_equal(last, ref.process(x[nh - 1:nh, :256])[0])
+    handles[-1].delete()
+    other.delete()
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] < 64 << 20  # everything came back, the shared images included
