@@ -61,6 +61,8 @@ bool Engine::drain_async(std::string *) { return true; }
 bool Engine::async_wait(int, std::string *) { return true; }
 bool Engine::reset(const uint8_t *, std::string *) { return true; }
 bool Engine::synchronize(std::string *) { return true; }
+void Engine::set_stream(hipStream_t s) { stream_ = s ? s : own_stream_; }
+size_t Engine::shared_device_bytes() const { return 0; }
 void Engine::profile_enable(bool on) { profiling_ = on; }
 bool Engine::profile_read(double *ms, int64_t *launches, std::string *) {
     for (int i = 0; i < kNumKernelClasses; ++i) ms[i] = 0.0, launches[i] = 0;
