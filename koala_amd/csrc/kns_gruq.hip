@@ -135,7 +135,11 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad1_kernel(GruQuadArgs 
 #pragma unroll
     for (int q = 0; q < kWF; ++q) {
         const int i = wave + kQWaves * q;
+#ifndef Q1_T_NOFETCH
         if (i < 3 * NBX)
+#else
+        if (false)
+#endif
             __builtin_amdgcn_global_load_lds((gptr_t) ((const frag_t *) g.wih + ((size_t) 48 * NBX + i) * 64 + lane),
                                              (lptr_t) (smem + kQ1OffW16x + i * 1024), 16, 0, 0);
     }
@@ -214,8 +218,14 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad1_kernel(GruQuadArgs 
         const frag_t *wih = (const frag_t *) g.wih + (size_t) (u * 3) * NBX * 64 + lane;  // [gate][k-block] fragments of tile u
         frag_t w[3][NBX];
         auto request = [&](const int blk) {
+#ifdef Q1_T_NOFETCH  // TIMING ONLY (garbage): as if the weights were already on the CU -- the bound on cross-call residency
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt) asm volatile("" : "=v"(w[gt][blk]));
+            (void) wih;
+#else
 #pragma unroll
             for (int gt = 0; gt < 3; ++gt) w[gt][blk] = wih[(gt * NBX + blk) * 64];
+#endif
         };
 #pragma unroll
         for (int blk = 0; blk < kQ1Ahead && blk < NBX; ++blk) request(blk);
@@ -286,9 +296,16 @@ __global__ __launch_bounds__(64 * kQWaves, 2) void gru_quad1_kernel(GruQuadArgs 
     const frag_t *whh16 = (const frag_t *) g.whh + (size_t) (16 * 3 + (j < 3 ? j : 0)) * 9 * 64 + lane;
     frag_t w[9][3], w16[9];
     auto request = [&](const int blk) {
+#ifdef Q1_T_NOFETCH
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt) asm volatile("" : "=v"(w[blk][gt]));
+        asm volatile("" : "=v"(w16[blk]));
+        (void) whh, (void) whh16;
+#else
 #pragma unroll
         for (int gt = 0; gt < 3; ++gt) w[blk][gt] = whh[(gt * 9 + blk) * 64];
         w16[blk] = whh16[blk * 64];  // (used by waves 0..2; requested by all four: no conditional load in the stream)
+#endif
     };
 #pragma unroll
     for (int blk = 0; blk < kQ1Ahead && blk < 9; ++blk) request(blk);
