@@ -529,6 +529,10 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     dev_wave_mt_ = dev_int("KOALA_AMD_WAVE_MT", -1);  // -1: the measured limits; 0: never
     dev_wave_group_ = dev_int("KOALA_AMD_WAVE_GROUP", 0);
     dev_wave_parts_ = dev_int("KOALA_AMD_WAVE_PARTS", 1);  // 0: a layer never takes more than one XCD
+    dev_pipe_chunk_ = dev_int("KOALA_AMD_PIPE_CHUNK", 0);  // frames per sub-chunk of the layer pipeline of mid-size batches (0: 16)
+    dev_pipe_streams_ = dev_int("KOALA_AMD_PIPE_STREAMS", 0);  // streams of the pipeline (0: the default, at most 4)
+    dev_pipe_grid_ = dev_int("KOALA_AMD_PIPE_GRID", 0);    // workgroups of its weight-stationary GEMM launches (0: the default)
+    dev_pipe_mt_ = dev_int("KOALA_AMD_PIPE_MT", -1);       // up to this many m-tiles (-1: the measured limit; 0: never)
     // One-frame calls of large batches: a GRU layer as ONE launch fused over CU quads (kns_gruq.hip, gru_quad1_kernel), bit-identical
     // to the two-kernel form -- a CU pulls a quarter of W_ih and W_hh (300 KiB) per layer instead of a half of one and all of the
     // other (~740 KiB): 128 against 222 us per 4096-stream frame step.  (The multi-frame form of that decomposition measured slower
@@ -713,6 +717,14 @@ Engine::~Engine() {
         if (ev_done_[i]) (void) hipEventDestroy(ev_done_[i]);
         if (ev_out_[i]) (void) hipEventDestroy(ev_out_[i]);
     }
+    for (int i = 0; i < kPipeStreams; ++i) {
+        if (pipe_stream_[i]) (void) hipStreamSynchronize(pipe_stream_[i]), (void) hipStreamDestroy(pipe_stream_[i]);
+        if (pipe_join_[i]) (void) hipEventDestroy(pipe_join_[i]);
+    }
+    if (pipe_fork_) (void) hipEventDestroy(pipe_fork_);
+    for (int i = 0; i < kPipeRing; ++i)
+        for (int l = 0; l < kGruLayers; ++l)
+            if (pipe_ev_[i][l]) (void) hipEventDestroy(pipe_ev_[i][l]);
     if (copy_in_) (void) hipStreamDestroy(copy_in_);
     if (copy_out_) (void) hipStreamDestroy(copy_out_);
     if (own_stream_) (void) hipStreamDestroy(own_stream_);
@@ -899,6 +911,28 @@ bool Engine::wave_fits() const {  // every head either goes into the features' p
     return true;
 }
 
+// streams and events of the layer pipeline (run_device), made on first use
+bool Engine::pipe_ready() {
+    if (pipe_ok_) return true;
+    if (pipe_failed_) return false;
+    bool ok = true;
+    for (int i = 0; i < kPipeStreams && ok; ++i) {
+        if (!pipe_stream_[i]) ok = hipStreamCreateWithFlags(&pipe_stream_[i], hipStreamNonBlocking) == hipSuccess;
+        if (ok && !pipe_join_[i]) ok = hipEventCreateWithFlags(&pipe_join_[i], hipEventDisableTiming) == hipSuccess;
+    }
+    if (ok && !pipe_fork_) ok = hipEventCreateWithFlags(&pipe_fork_, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < kPipeRing && ok; ++i)
+        for (int l = 0; l < kGruLayers && ok; ++l)
+            if (!pipe_ev_[i][l]) ok = hipEventCreateWithFlags(&pipe_ev_[i][l], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        (void) hipGetLastError();
+        pipe_failed_ = true;  // (the plain chunked route stays)
+        return false;
+    }
+    pipe_ok_ = true;
+    return true;
+}
+
 void Engine::run_wave(int T, int mtb) {
     // m-tiles per workgroup (an XCD holds 64 workgroups at a time, a layer has 17 per group; measured best: 1 up to 64 streams,
     // 3 up to 256 (fp32: 512), then 6 in bf16, 4 up to 2 048 and 8 beyond in fp32 -- short groups balance the CUs, long ones pull the
@@ -980,11 +1014,10 @@ void Engine::run_wave(int T, int mtb) {
 //   | mask head                     | inside the synthesis launch                         | gemm_wsr_kernel                      |
 //   | analysis / synthesis segments | one                                                 | ~4 / ~2 workgroups per CU (>= 1 frame)  |
 //   Host-pointer calls: >= 4 MiB and more than min(16, max_frames / 2) frames -> sub-chunks on three streams; T = 1 -> hipGraph replay.
-enum Route { kRouteChunked = 0, kRouteSmall = 1, kRouteSmallSteps = 2, kRouteQuad1 = 3, kRouteWave = 4 };
+enum Route { kRouteChunked = 0, kRouteSmall = 1, kRouteSmallSteps = 2, kRouteQuad1 = 3, kRouteWave = 4, kRoutePipelined = 5 };
 
 bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string *err, bool allow_recompute) {
     const int mtb = Bpad_ / 16;
-    const int M = mtb * T;
     last_T_ = T;
 
     AnalysisArgs an;
@@ -1040,6 +1073,11 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     tock(kClsAnalysis);
     if (!in_place) hist_cur_ ^= 1;
 
+    // Time slice of the call the launches below work on, and where they go: the whole call on the handle's stream -- or, for mid-size
+    // batches, one of its sub-chunks on one of the pipeline streams (run_pipelined below).  Every activation matrix is frame-major
+    // ([frame][m-tile][blocks]), so a slice of frames is a contiguous slice of each of them.
+    int c_t0 = 0, c_T = T, c_hs = hs_cur_, c_grid = 0;
+    hipStream_t c_stream = stream_;
     auto gemm = [&](int cls, const void *a0, int nb0, const void *a1, int nb1, const void *w, const float *bias,
                     void *out, int ntiles, int n_valid, int kind, int taps = 1, int pad_nb = 0, int pad_blk = 0, int pad_kk0 = 0) {
         GemmArgs g;
@@ -1048,46 +1086,52 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         g.pad_kk0 = pad_kk0;
         g.taps = taps;
         g.tap_stride = feat_frame_bytes_;
-        g.a0 = a0;
-        g.a1 = a1;
+        const size_t m0 = (size_t) c_t0 * mtb;  // first m-tile of the slice
+        const size_t out_stride = kind == kOutGi ? (size_t) kGateTiles * 64 * pi_.gisz
+                                  : kind == kOutMask ? (size_t) kMaskTiles * 256 * (prec_ == kBf16 ? 2 : 4)
+                                                     : (size_t) (pad_nb ? pad_nb : (ntiles + pi_.npb - 1) / pi_.npb) * 1024;
+        g.a0 = a0 ? (const char *) a0 + m0 * nb0 * 1024 : nullptr;
+        g.a1 = (const char *) a1 + m0 * nb1 * 1024;
         g.w = w;
         g.bias = bias;
-        g.out = out;
+        g.out = (char *) out + m0 * out_stride;
         g.nb0 = nb0;
         g.nb1 = nb1;
-        g.mtiles = M;
+        g.mtiles = mtb * c_T;
         g.ntiles = ntiles;
         g.n_valid = n_valid;
         g.out_kind = kind;
         g.precision = prec_;
         g.dev = dev_variant_;
+        g.grid = c_grid;
         tick(cls);
-        if (only < 0 || only == cls) launch_gemm(g, stream_);
+        if (only < 0 || only == cls) launch_gemm(g, c_stream);
         tock(cls);
     };
     auto gru = [&](const void *whh, const float *bhh, int layer, void *hseq, const StageDev *head = nullptr) {
         GruArgs g;
+        const size_t m0 = (size_t) c_t0 * mtb;
         if (head) {  // this stage's narrow head inside the launch, into the padding of the feature matrix (kns_kernels.h)
             g.yw = head->w_head;
             g.yb = head->b_head;
-            g.yout = feat_now;
+            g.yout = feat_now + (size_t) c_t0 * feat_frame_bytes_;
             g.yvalid = head->head_dim;
             g.y_nb = nbf_;
             g.y_blk = kBins / pi_.kb;
             g.y_kk0 = kBins % pi_.kb;
         }
-        g.gi = d_gi_;
+        g.gi = (const char *) d_gi_ + m0 * kGateTiles * 64 * pi_.gisz;
         g.whh = whh;
         g.bhh = bhh;
-        g.hstate_in = d_hstate_[hs_cur_] + (size_t) layer * mtb * kUnitTiles * 256;
-        g.hstate_out = d_hstate_[hs_cur_ ^ 1] + (size_t) layer * mtb * kUnitTiles * 256;
-        g.hseq = hseq;
-        g.T = T;
+        g.hstate_in = d_hstate_[c_hs] + (size_t) layer * mtb * kUnitTiles * 256;
+        g.hstate_out = d_hstate_[c_hs ^ 1] + (size_t) layer * mtb * kUnitTiles * 256;
+        g.hseq = (char *) hseq + m0 * nbh_ * 1024;
+        g.T = c_T;
         g.mtiles = mtb;
         g.precision = prec_;
         g.dev = dev_variant_;
         tick(kClsGru);
-        if (only < 0 || only == kClsGru) launch_gru(g, stream_);
+        if (only < 0 || only == kClsGru) launch_gru(g, c_stream);
         tock(kClsGru);
     };
 
@@ -1179,7 +1223,43 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
             gemm(kClsGemmHead, nullptr, 0, d_hseq_b_, nbh_, sd_[kStages - 1].w_head, sd_[kStages - 1].b_head, d_mask_,
                  sd_[kStages - 1].head_tiles, kBins, kOutMask);
     }
-    for (int s = 0; s < kStages && !wave; ++s) {
+    // Mid-size batches (round 6): with fewer than ~160 m-tiles the weight-resident recurrent launches occupy as many CUs and take the
+    // same ~150 us per 64 frames as with 256 -- at 1 024 streams eight of them are 1.23 of the call's 1.37 ms on a quarter of the chip.
+    // The layers of a call depend on each other frame by frame only, so the call is cut into sub-chunks of frames and the (layer, chunk)
+    // grid runs as a wavefront over two streams: chunk c's 18 launches in order on stream c mod S, its recurrent launch of layer l
+    // behind chunk c - 1's (an event per (chunk, layer)); up to S recurrent launches of different layers then share the chip.  Same
+    // kernels on slices of the same buffers: the same bits (chunking is invisible).  Hidden state: chunk c reads ping-pong buffer
+    // (hs_cur_ + c) & 1 and writes the other one.
+    // Measured (tools/pipe_sweep.py, profiles/r06_pipe_sweep.txt): TWO sub-chunks on two streams is the best form at every size -- 64 frames x
+    // 1 024 streams 1.34 -> 1.06 ms, x 2 048 streams 1.68 -> 1.48 ms; three chunks equal it, four and more lose (a launch of 8-16 frames is
+    // mostly prologue, and every cross-stream event costs microseconds) -- and it stops paying at 160 m-tiles.
+    const int pipe_chunk = dev_pipe_chunk_ > 0 ? dev_pipe_chunk_ : (T + 1) / 2;
+    const int pipe_mt = dev_pipe_mt_ >= 0 ? dev_pipe_mt_ : 144;
+    const int pipe_grid = dev_pipe_grid_ > 0 ? dev_pipe_grid_ : 128;
+    const int pipe_streams = dev_pipe_streams_ > 0 && dev_pipe_streams_ <= kPipeStreams ? dev_pipe_streams_ : 2;
+    const bool pipelined = !wave && !small && !small_steps && !quad && prec_ == kBf16 && mtb <= pipe_mt && T >= 32 && T >= 2 * pipe_chunk - 1 && !profiling_ &&
+                           !debug_taps_ && only < 0 && pipe_ready();
+    int nchunks = 1;
+    if (pipelined) {
+        nchunks = (T + pipe_chunk - 1) / pipe_chunk;
+        if (T - (nchunks - 1) * pipe_chunk < pipe_chunk / 2 && nchunks > 2) --nchunks;  // (a short tail joins the last chunk)
+        (void) hipEventRecord(pipe_fork_, stream_);
+    }
+    for (int c = 0; c < nchunks && !wave; ++c) {
+      if (pipelined) {
+          c_t0 = c * pipe_chunk;
+          c_T = c == nchunks - 1 ? T - c_t0 : pipe_chunk;
+          c_hs = (hs_cur_ + c) & 1;
+          c_stream = pipe_stream_[c % pipe_streams];
+          c_grid = pipe_grid;
+          if (c < pipe_streams) (void) hipStreamWaitEvent(c_stream, pipe_fork_, 0);
+      }
+      auto gru_dep = [&](const void *whh, const float *bhh, int layer, void *hseq, const StageDev *head = nullptr) {
+          if (pipelined && c > 0) (void) hipStreamWaitEvent(c_stream, pipe_ev_[(c - 1) % kPipeRing][layer], 0);
+          gru(whh, bhh, layer, hseq, head);
+          if (pipelined && c + 1 < nchunks) (void) hipEventRecord(pipe_ev_[c % kPipeRing][layer], c_stream);
+      };
+      for (int s = 0; s < kStages; ++s) {
         const StageDev &d = sd_[s];
         head_in_recurrent = false;
         // (d.ypad: the previous head's few values sit in the padding of the features' last k-block -- no y part of its own)
@@ -1197,7 +1277,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
                 gru_quad(yprev, nby, stage_in, d.w_ih_a, d.b_ih_a, d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_, head_in_next ? &sd_[s - 1] : nullptr);
             } else {
                 gemm(kClsGemmIn, yprev, nby, stage_in, nbh_, d.w_ih_a, d.b_ih_a, d_gi_, kGateTiles, 3 * kHidden, kOutGi);
-                gru(d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_);
+                gru_dep(d.w_hh_a, d.b_hh_a, 2 * s, d_hseq_a_);
             }
             if (quad) {
                 gru_quad(nullptr, 0, d_hseq_a_, d.w_ih_b, d.b_ih_b, d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_);
@@ -1208,7 +1288,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
                 head_in_recurrent = T > 1 && s < kStages - 1 && sd_[s + 1].ypad && d.head_tiles == pi_.npb && fuse_head_ && !debug_taps_ &&
                                     !(dev_variant_ & kDevGruStream);
                 gemm(kClsGemmIn, nullptr, 0, d_hseq_a_, nbh_, d.w_ih_b, d.b_ih_b, d_gi_, kGateTiles, 3 * kHidden, kOutGi);
-                gru(d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_, head_in_recurrent ? &d : nullptr);
+                gru_dep(d.w_hh_b, d.b_hh_b, 2 * s + 1, d_hseq_b_, head_in_recurrent ? &d : nullptr);
             }
         }
         head_in_next = s < kStages - 1 && T == 1 && fuse_head_ && nby_[s] >= 1 && d.head_tiles == pi_.npb * nby_[s] && !debug_taps_ &&
@@ -1224,6 +1304,12 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         else if (!mask_in_synthesis)
             gemm(kClsGemmHead, nullptr, 0, d_hseq_b_, nbh_, d.w_head, d.b_head, d_mask_, d.head_tiles, kBins, kOutMask);
     }
+      if (pipelined && (c >= nchunks - pipe_streams)) {  // the last chunk of each stream: the handle's stream continues behind it
+          (void) hipEventRecord(pipe_join_[c % pipe_streams], c_stream);
+          (void) hipStreamWaitEvent(stream_, pipe_join_[c % pipe_streams], 0);
+      }
+    }
+    c_t0 = 0, c_T = T, c_hs = hs_cur_, c_stream = stream_, c_grid = 0;
 
     SynthesisArgs sy;
     sy.spec = d_spec_;
@@ -1256,7 +1342,8 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     tick(kClsSynthesis);
     if (only < 0 || only == kClsSynthesis) launch_synthesis(sy, stream_);
     tock(kClsSynthesis);
-    hs_cur_ = small_steps || wave ? (hs_cur_ + T) & 1 : hs_cur_ ^ 1;
+    hs_cur_ = small_steps || wave ? (hs_cur_ + T) & 1 : pipelined ? (hs_cur_ + nchunks) & 1 : hs_cur_ ^ 1;
+    if (pipelined) last_route_ = kRoutePipelined;
     if (!in_place) tail_cur_ ^= 1;
 
     hipError_t e = hipGetLastError();

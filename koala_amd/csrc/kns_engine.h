@@ -133,6 +133,12 @@ private:
                             const float *bhh, int layer, void *hseq, int t, const StageDev *head) const;
     GruWaveItem wave_item(int i, int t, int mtb) const;
     bool wave_fits() const;
+    // mid-size batches: the (layer, chunk-of-frames) grid of a call as a wavefront over a few streams (kns_engine.cpp, run_device)
+    static constexpr int kPipeStreams = 4, kPipeRing = 2;
+    hipStream_t pipe_stream_[kPipeStreams] = {};
+    hipEvent_t pipe_fork_ = nullptr, pipe_join_[kPipeStreams] = {}, pipe_ev_[kPipeRing][kGruLayers] = {};
+    bool pipe_ok_ = false, pipe_failed_ = false;
+    bool pipe_ready();
     void run_wave(int T, int mtb);
     // asynchronous host calls: two slots of full-size device staging (slot 0 = d_in_ / d_out_, slot 1 allocated on first use)
     int16_t *d_in2_ = nullptr, *d_out2_ = nullptr;
@@ -155,7 +161,7 @@ private:
     bool spin_wait_ = true;
     bool use_graph_ = true, no_small_ = false, no_zero_copy_ = false, no_recompute_ = false, debug_taps_ = false;
     // developer switches (all read once in init() through dev_env(): compiled out of the product library)
-    int dev_variant_ = 0, dev_only_class_ = -1, dev_analysis_seg_ = 0, dev_synth_seg_ = 0, dev_small_mt_ = 0, dev_steps_mt_ = 192, dev_wave_mt_ = -1, dev_wave_group_ = 0, dev_wave_parts_ = 1;
+    int dev_variant_ = 0, dev_only_class_ = -1, dev_analysis_seg_ = 0, dev_synth_seg_ = 0, dev_small_mt_ = 0, dev_steps_mt_ = 192, dev_wave_mt_ = -1, dev_wave_group_ = 0, dev_wave_parts_ = 1, dev_pipe_chunk_ = 0, dev_pipe_mt_ = -1, dev_pipe_grid_ = 0, dev_pipe_streams_ = 0;
     // one-frame calls: GRU layers fused over CU quads (kns_gruq.hip); narrow heads / front-end / mask head inside their consumers
     bool use_quad_ = true;
     int quad_nb0_max_ = 2;

@@ -771,7 +771,10 @@ void launch_gemm(const GemmArgs &a, hipStream_t s) {
         // for bit (tests/test_gpu_parity.py::test_alternative_kernels_give_identical_pcm).
         GemmArgs m = a;
         m.mtiles = a.mtiles / 256 * 256;
-        const dim3 grid(256), block(64 * kWs2Waves);
+        // (a narrower grid -- GemmArgs::grid, whole groups of 16 workgroups -- walks more stages per workgroup pair; 256 = 2 x grid / 2 x
+        // stage divides by every such grid)
+        const int wgs = a.grid >= 16 && a.grid < 256 ? (a.grid / 16 >= 8 ? 128 : a.grid / 16 >= 4 ? 64 : a.grid / 16 >= 2 ? 32 : 16) : 256;
+        const dim3 grid(wgs), block(64 * kWs2Waves);
         if (m.mtiles % 512 == 0) {  // four m-tiles per barrier
             if (a.nb0 == 0)  // (eight per barrier measured the same)
                 hipLaunchKernelGGL((gemm_ws2_kernel<0, 4>), grid, block, 0, s, m);
@@ -821,7 +824,7 @@ void launch_gemm(const GemmArgs &a, hipStream_t s) {
         }
     }
     if (a.precision == kBf16 && a.nb0 == 0 && a.nb1 == PBF16::NBH && a.taps == 1 && a.mtiles >= 512 && !no_wsr) {
-        const dim3 grid(256), block(512);
+        const dim3 grid(a.grid >= 16 && a.grid < 256 ? a.grid : 256), block(512);
         if (a.out_kind == kOutAPlain && a.ntiles <= 32) {
             hipLaunchKernelGGL((gemm_wsr_kernel<kOutAPlain, 2>), grid, block, 0, s, a);
             return;

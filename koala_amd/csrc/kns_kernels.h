@@ -105,6 +105,9 @@ struct GemmArgs {
     // written INTO block pad_blk of an existing A-packed matrix with pad_nb blocks per m-tile, at columns pad_kk0 ... of that block
     // (2-byte elements; everything else of the block is left alone) -- a narrow head's values in the padding of the feature matrix
     int pad_nb = 0, pad_blk = 0, pad_kk0 = 0;
+    // workgroups of the weight-stationary kernels (0: one per CU, 256).  The layer pipeline of mid-size batches launches them narrower,
+    // beside the recurrent launches of other layers that hold most of the chip: a grid that does not fit waits for whole CUs
+    int grid = 0;
 };
 void launch_gemm(const GemmArgs &a, hipStream_t s);
 

@@ -382,7 +382,8 @@ import koala_amd
 from koala_amd.workload import synth_streams
 h = hashlib.sha256()
 for precision, B, T in (('bf16', 4096, 4), ('bf16', 4096, 1), ('bf16', 272, 3), ('bf16', 320, 5), ('fp32', 512, 2), ('bf16', 272, 1),
-                        ('fp32', 48, 1), ('bf16', 960, 1), ('fp32', 48, 7), ('fp32', 250, 8), ('bf16', 512, 6)):  # (the last three: the wavefront route)
+                        ('fp32', 48, 1), ('bf16', 960, 1), ('fp32', 48, 7), ('fp32', 250, 8), ('bf16', 512, 6),  # (the last three: the wavefront route)
+                        ('bf16', 1040, 37), ('bf16', 2048, 32)):  # (the layer pipeline over sub-chunks of frames, mid-size batches)
     x = np.tile(synth_streams(16, 2 * T, seed=9), ((B + 15) // 16, 1))[:B]
     kb = koala_amd.create_batch('key', B, T, precision, model_path=%(model)r, library_path=%(lib)r)
     for c in range(2):
@@ -419,10 +420,12 @@ def test_alternative_kernels_give_identical_pcm(random_model, random5_model):
     for switch in ('', 'KOALA_AMD_GRU_STREAM', 'KOALA_AMD_GEMM_GENERIC',
                    'KOALA_AMD_GEMM_NO_WSR', 'KOALA_AMD_NO_SMALL', 'KOALA_AMD_NO_GRAPH', 'KOALA_AMD_STORE_SPECTRUM',
                    'KOALA_AMD_DEBUG_TAPS', 'KOALA_AMD_NO_QUAD', 'KOALA_AMD_NO_HEAD_FUSE', 'KOALA_AMD_NO_STFT_FUSE', 'KOALA_AMD_WAVE_MT=0',
-                   'KOALA_AMD_WAVE_MT=4096', 'KOALA_AMD_WAVE_GROUP=2', 'KOALA_AMD_NO_SPIN_WAIT'):  # (KOALA_AMD_NO_QUAD: one-frame calls of large
+                   'KOALA_AMD_WAVE_MT=4096', 'KOALA_AMD_WAVE_GROUP=2', 'KOALA_AMD_NO_SPIN_WAIT', 'KOALA_AMD_PIPE_MT=0', 'KOALA_AMD_PIPE_CHUNK=8',
+                   'KOALA_AMD_NO_WEIGHT_CACHE'):  # (KOALA_AMD_NO_QUAD: one-frame calls of large
         # batches through input GEMM + recurrent kernel instead of the one-step quad kernel, kns_gruq.hip; KOALA_AMD_WAVE_MT: multi-frame
         # calls never / always as a wavefront over (layer, frame), kns_gru.hip gru_wave_kernel; _GROUP: its m-tiles per workgroup;
-        # KOALA_AMD_NO_SPIN_WAIT: one-frame host calls wait in hipStreamSynchronize instead of spinning on the frame's completion word)
+        # KOALA_AMD_NO_SPIN_WAIT: one-frame host calls wait in hipStreamSynchronize instead of spinning on the frame's completion word;
+        # KOALA_AMD_PIPE_MT=0: mid-size batches never as a layer pipeline over sub-chunks of frames, _CHUNK: its frames per sub-chunk)
         env = dict(os.environ)
         if switch:
             env[switch.split('=')[0]] = switch.split('=')[1] if '=' in switch else '1'
@@ -881,3 +884,33 @@ def test_many_single_stream_handles_share_one_weight_image(random_model, gate_mo
     other.delete()
     torch.cuda.synchronize()
     assert free0 - torch.cuda.mem_get_info()[0] < 64 << 20  # everything came back, the shared images included
+
+
+@pytest.mark.parametrize('B,T', [(1024, 64), (1040, 41), (2048, 32), (800, 57), (2560, 64)])
+def test_mid_size_batches_through_the_layer_pipeline(random_model, B, T):
+    """Mid-size batches (49 .. 144 m-tiles, >= 32 frames per call) run their (layer, sub-chunk of frames) grid as a wavefront over two
+    streams (kns_engine.cpp run_device, kRoutePipelined): the same kernels on slices of the same buffers.  Two calls (the second one
+    continues the streams from ping-pong state buffers the first one left in either parity), 128 distinct streams against the oracle,
+    every replica identical, and device pointers on a caller's stream."""
+    torch = pytest.importorskip('torch')
+    base = synth_streams(128, 2 * T, seed=B + T)
+    x = np.tile(base, ((B + 127) // 128, 1))[:B]
+    kb = koala_amd.create_batch('key', B, T, 'bf16', model_path=random_model, library_path=DEV_LIB)
+    ref = oracle.Oracle(random_model, 128, oracle.PREC_BF16)
+    st = torch.cuda.Stream()
+    kb.set_stream(st.cuda_stream)
+    for c in range(2):
+        dx = torch.from_numpy(np.ascontiguousarray(x[:, c * T * 256:(c + 1) * T * 256])).cuda()
+        dy = torch.zeros_like(dx)
+        torch.cuda.synchronize()
+        kb.process_device(T, dx.data_ptr(), dy.data_ptr())
+        kb.synchronize()
+        if c == 0:
+            assert int(kb.debug_read('route', T)[0]) == (5 if B <= 2304 else 0)
+        y = dy.cpu().numpy()
+        want = ref.process(np.ascontiguousarray(base[:, c * T * 256:(c + 1) * T * 256]))
+        assert lsb(y[:128], want).max() <= BF16_TOL
+        for i in range(128, B):
+            assert np.array_equal(y[i], y[i % 128]), i
+    kb.set_stream(0)
+    kb.delete()
