@@ -725,6 +725,7 @@ Engine::~Engine() {
     for (int i = 0; i < kPipeRing; ++i)
         for (int l = 0; l < kGruLayers; ++l)
             if (pipe_ev_[i][l]) (void) hipEventDestroy(pipe_ev_[i][l]);
+    if (host_fork_) (void) hipEventDestroy(host_fork_);
     if (copy_in_) (void) hipStreamDestroy(copy_in_);
     if (copy_out_) (void) hipStreamDestroy(copy_out_);
     if (own_stream_) (void) hipStreamDestroy(own_stream_);
@@ -1639,7 +1640,22 @@ bool Engine::process(int T, const int16_t *pcm, int16_t *out, std::string *err, 
                    "disjoint buffers.";
             return false;
         }
-        return process_host_pipelined(T, pcm, out, kin == kPtrPinned && kout == kPtrPinned, err);
+        // On a caller's stream the kernels of the sub-chunks still run on the handle's OWN stream, fenced behind whatever the caller
+        // has enqueued (the call is synchronous, so everything the caller enqueues later is behind it anyway): the handle's three
+        // streams were created together and sit on three different hardware queues, while a foreign stream may share its queue with
+        // one of the copy streams -- measured: 40 instead of 62 M frames/s for page-locked buffers (profiles/r06_bench.json notes)
+        hipStream_t user = stream_;
+        if (user != own_stream_ && !profiling_) {
+            if (!host_fork_ && hipEventCreateWithFlags(&host_fork_, hipEventDisableTiming) != hipSuccess) {
+                (void) hipGetLastError();
+                host_fork_ = nullptr;
+            }
+            if (host_fork_ && hipEventRecord(host_fork_, user) == hipSuccess && hipStreamWaitEvent(own_stream_, host_fork_, 0) == hipSuccess)
+                stream_ = own_stream_;
+        }
+        const bool done = process_host_pipelined(T, pcm, out, kin == kPtrPinned && kout == kPtrPinned, err);
+        stream_ = user;
+        return done;
     }
     memcpy(h_in_, pcm, bytes);
     if (T == 1 && use_graph_ && stream_ == own_stream_ && !profiling_) {

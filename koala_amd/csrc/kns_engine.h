@@ -147,6 +147,7 @@ private:
     bool async_busy_[4] = {false, false, false, false};  // by call number mod 4: the window is three calls
     unsigned async_n_ = 0;
     hipStream_t copy_in_ = nullptr, copy_out_ = nullptr;
+    hipEvent_t host_fork_ = nullptr;  // synchronous host calls on a caller's stream: the handle's own stream waits behind it
     hipEvent_t ev_in_[2] = {nullptr, nullptr}, ev_done_[2] = {nullptr, nullptr}, ev_out_[2] = {nullptr, nullptr};
     int host_chunk_ = 1;
     size_t host_pipeline_min_bytes_ = 0;
