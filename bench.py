@@ -653,6 +653,14 @@ def main():
                             'when': 'last second of priming (rocm-smi from a host thread while the step runs)'}
         prime['steps'] += 8  # the group still in flight: it runs straight into the warm-up steps below
     prime['seconds'] = round(time.perf_counter() - t_prime, 2)
+    if collective and args.prime_seconds > 0:
+        # several ranks: priming ends at a different moment on every rank, and waiting for the slowest one at the barrier below would
+        # leave the other boards idle for tenths of a second -- the sag priming exists to avoid.  So the ranks are aligned HERE, run a
+        # fixed stretch of the step back to back again (~60 ms), and meet the barrier in front of the timed region within a millisecond
+        barrier()
+        for _ in range(24):
+            step()
+        prime['steps'] += 24
     for _ in range(args.warmup):
         step()
     barrier()

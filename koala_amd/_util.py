@@ -49,7 +49,7 @@ def build_native(force: bool = False) -> str:
             finally:
                 fcntl.flock(lock, fcntl.LOCK_UN)
     model = default_model_path()
-    tag, kind = model + '.kind', 'adaptive-gate-v3'
+    tag, kind = model + '.kind', 'adaptive-gate-v4'
     if not os.path.exists(model) or not os.path.exists(tag) or open(tag).read().strip() != kind:
         from . import params
         params.write_params(model, params.make_adaptive_gate())

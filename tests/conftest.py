@@ -34,7 +34,7 @@ def load_wav(name):
 def model_file(kind, seed=1234):
     from koala_amd import params
     # (the default model's file carries the version of its constants: a stale build/ directory must not serve round 4's hard gate)
-    name = '%s_%d.kns' % (kind, seed) if kind.startswith('random') else 'adaptive_v3.kns' if kind == 'adaptive' else '%s.kns' % kind
+    name = '%s_%d.kns' % (kind, seed) if kind.startswith('random') else 'adaptive_v4.kns' if kind == 'adaptive' else '%s.kns' % kind
     if kind == 'gate':  # round 1's fixture-calibrated gate: its threshold is derived HERE from the reference's noise fixture
         return params.ensure_params(os.path.join(BUILD, name), kind, seed,
                                     threshold=params.noise_prior(load_wav('noise.wav')) + 2.15)

@@ -1,16 +1,16 @@
 """
-Hold-out check of the default model (koala_amd.params.make_adaptive_gate): its constants were tuned on the reference's
-acceptance envelope (test.wav / noise.wav / their mix), so here it meets noises that took no part in that -- seeded
-synthetic white, pink and low-frequency "rumble" noise at two levels, alone and mixed with the speech fixture -- and one
-it is NOT expected to handle: speech-like babble (amplitude-modulated formant resonances).  CPU oracle; the GPU engine is
-checked against the same oracle sample for sample elsewhere.
+Synthetic-noise check of the default model (koala_amd.params.make_adaptive_gate): seeded white, pink and low-frequency "rumble" noise
+at two levels, alone and mixed with the speech fixture -- and one kind it is NOT expected to handle: speech-like babble (amplitude-
+modulated formant resonances).  SINCE ROUND 5 THIS IS A TUNING SET, not a hold-out: tools/gate_search.py reads these very bars in its
+cost (the file keeps its name; the set no search has seen is tests/test_validation.py).  CPU oracle; the GPU engine is checked against
+the same oracle sample for sample elsewhere.
 
 Bars (levels 0.01 and 0.03 RMS, i.e. around and above the reference's noise fixture at 0.023): stationary noise alone is
-suppressed by >= 15 dB after 0.5 s (measured 16.7-23.5 dB with round 5's constants; round 4's hard gate: 21-33 dB, at the price of a
-bf16 path that amplified single rounding flips -- DESIGN.md section 2.4) and by >= 8 dB in the first four frames, while the floor
-tracker is still coming down from its closed start (measured 9.2-9.8 dB; the reference's own test checks those frames against an
-absolute 0.02 RMS, test_koala.py:94-95); with speech on top, speech-active frames keep >= 85 % (median) of the clean speech's RMS
-(measured 0.86-0.95).  Babble: what is measured is recorded (7 dB), the bar is only "does no harm".
+suppressed by >= 20 dB after 0.5 s (measured 21.3-28.9 dB with round 6's constants, adaptive-gate-v4; round 5's v3: 16.7-23.5 dB; round 4's
+hard gate: 21-33 dB, at the price of a bf16 path that amplified single rounding flips -- DESIGN.md section 2.4) and by >= 9 dB in the first
+four frames, while the floor tracker is still coming down from its closed start (measured 9.6-10.7 dB; the reference's own test checks
+those frames against an absolute 0.02 RMS, test_koala.py:94-95); with speech on top, speech-active frames keep >= 85 % (median) of the clean
+speech's RMS (measured 0.87-0.97).  Babble: what is measured is recorded (10 dB), the bar is only "does no harm".
 """
 import numpy as np
 import pytest
@@ -68,8 +68,8 @@ def run_case(kind, level, test_pcm, engine=None):
 def test_stationary_holdout_noise(kind, level, test_pcm):
     r = run_case(kind, level, test_pcm)
     print(kind, level, r)
-    assert r['steady_db'] >= 15.0, r
-    assert r['first_frames_db'] >= 8.0, r
+    assert r['steady_db'] >= 20.0, r
+    assert r['first_frames_db'] >= 9.0, r
     assert r['speech_ratio'] >= 0.85, r
 
 
@@ -95,7 +95,7 @@ def test_holdout_noise_through_the_gpu_engine(precision, test_pcm):
         for level in (0.01, 0.03):
             r = run_case(kind, level, test_pcm, engine)
             print(precision, kind, level, r)
-            assert r['steady_db'] >= 15.0 and r['first_frames_db'] >= 8.0 and r['speech_ratio'] >= 0.85, (kind, level, r)
+            assert r['steady_db'] >= 20.0 and r['first_frames_db'] >= 9.0 and r['speech_ratio'] >= 0.85, (kind, level, r)
     r = run_case('babble', 0.01, test_pcm, engine)
     print(precision, 'babble', r)
     assert r['steady_db'] >= 3.0 and r['speech_ratio'] >= 0.9, r
@@ -142,9 +142,10 @@ def test_default_model_is_insensitive_to_the_last_bits_of_the_bf16_configuration
 def test_rising_noise_level_is_a_known_limitation():
     """What the default model does NOT do, recorded so that nobody has to find out: its floor tracker falls fast and rises very slowly
     (that asymmetry is what protects speech), so a noise level that steps UP is treated like speech for a long time -- white noise at
-    0.01 RMS is suppressed by ~19 dB, and after a +6 dB step by ~7 dB still 18 s later (+12 dB: ~2 dB).  Neither the reference's envelope
-    nor the cases above contain a rising level.  The bar is only that the engine does no harm (never amplifies) and that the level
-    BEFORE the step is handled like any stationary noise."""
+    0.01 RMS is suppressed by ~29 dB, and after a +6 dB step by ~10 dB still 18 s later (round 5's constants: 19 and 7 dB).  Since round 6 the
+    constant search scores a rising level (tools/gate_search.py, `rising`), which bought those 3 dB and rejects constants that freeze the
+    floor; the tracker's structure still does not follow a step within seconds.  The bar: never amplifies, the level BEFORE the step is
+    handled like any stationary noise, and >= 8 dB are kept after it."""
     rng = np.random.default_rng(5)
     n = 16000 * 24 // 256 * 256
     g = np.where(np.arange(n) < 16000 * 4, 0.01, 0.02)
@@ -154,5 +155,5 @@ def test_rising_noise_level_is_a_known_limitation():
     sup = 20 * np.log10(fi[:-1] / np.maximum(fo[1:], 1e-9))
     before, late = float(np.median(sup[125:187])), float(np.median(sup[-187:-62]))
     print('white noise 0.01 RMS: %.1f dB; 18 s after a +6 dB step: %.1f dB' % (before, late))
-    assert before >= 15.0
-    assert late >= 0.0 and late < before  # recorded: the floor has not followed
+    assert before >= 20.0
+    assert late >= 8.0 and late < before  # recorded: the floor has not followed
