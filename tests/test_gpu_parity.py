@@ -933,3 +933,23 @@ def test_bf16_engine_against_the_round4_anchor(kind):
     d = lsb(y, r4['%s_bf16' % kind])
     print(kind, 'engine vs round-4 oracle: max %d LSB, %.3f %% within 1' % (int(d.max()), 100.0 * (d <= 1).mean()))
     assert d.max() <= BF16_TOL and (d <= 1).mean() >= 0.98
+
+
+@pytest.mark.parametrize('kind', ['random', 'adaptive'])
+def test_engine_against_the_independent_numpy_restatements(kind, test_pcm, noise_pcm):
+    """The engine held to the SPEC without the C oracle in between: the float64 numpy restatements of tests/test_oracle.py (KNS-v1 from
+    DESIGN.md section 2; the bf16 configuration's rounding points from section 2.2), which share no code with oracle/kns_oracle.c.  fp32
+    engine: within 1 LSB (float32 against float64 round-off at the final rounding), >= 99 % identical; bf16 engine: the suite's 5-LSB bar,
+    >= 97 % within 1."""
+    from test_oracle import _numpy_kns_v1, _numpy_kns_v1_bf16
+    model = model_file(kind)
+    a = 30 * 256
+    pcm = (test_pcm[a:a + 60 * 256].astype(int) + noise_pcm[a:a + 60 * 256]).astype(np.int16)
+    for precision, restatement, tol, share in (('fp32', _numpy_kns_v1, 1, 0.99), ('bf16', _numpy_kns_v1_bf16, BF16_TOL, 0.97)):
+        want, _ = restatement(model, pcm)
+        kb = koala_amd.create_batch('key', 1, 20, precision, model_path=model)
+        got = np.concatenate([kb.process(np.ascontiguousarray(pcm[None, c * 5120:(c + 1) * 5120])) for c in range(3)], axis=1)[0]
+        kb.delete()
+        d = lsb(got, want)
+        print(kind, precision, 'engine vs numpy restatement: max %d LSB, identical %.4f, within 1: %.4f' % (int(d.max()), float((d == 0).mean()), float((d <= 1).mean())))
+        assert d.max() <= tol and (d <= (0 if precision == 'fp32' else 1)).mean() >= share, (precision, int(d.max()))
