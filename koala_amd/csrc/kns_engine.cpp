@@ -530,6 +530,7 @@ bool Engine::init(const Params &p, int device, int B, int Tmax, int precision, s
     dev_wave_group_ = dev_int("KOALA_AMD_WAVE_GROUP", 0);
     dev_wave_parts_ = dev_int("KOALA_AMD_WAVE_PARTS", 1);  // 0: a layer never takes more than one XCD
     dev_pipe_chunk_ = dev_int("KOALA_AMD_PIPE_CHUNK", 0);  // frames per sub-chunk of the layer pipeline of mid-size batches (0: 16)
+    dev_pipe_whole_stft_ = dev_env("KOALA_AMD_PIPE_WHOLE_STFT") != nullptr;  // its analysis / synthesis as whole-call launches (A/B arm)
     dev_pipe_streams_ = dev_int("KOALA_AMD_PIPE_STREAMS", 0);  // streams of the pipeline (0: the default, at most 4)
     dev_pipe_grid_ = dev_int("KOALA_AMD_PIPE_GRID", 0);    // workgroups of its weight-stationary GEMM launches (0: the default)
     dev_pipe_mt_ = dev_int("KOALA_AMD_PIPE_MT", -1);       // up to this many m-tiles (-1: the measured limit; 0: never)
@@ -722,6 +723,8 @@ Engine::~Engine() {
         if (pipe_join_[i]) (void) hipEventDestroy(pipe_join_[i]);
     }
     if (pipe_fork_) (void) hipEventDestroy(pipe_fork_);
+    for (int i = 0; i < kPipeRing; ++i)
+        if (pipe_syn_[i]) (void) hipEventDestroy(pipe_syn_[i]);
     for (int i = 0; i < kPipeRing; ++i)
         for (int l = 0; l < kGruLayers; ++l)
             if (pipe_ev_[i][l]) (void) hipEventDestroy(pipe_ev_[i][l]);
@@ -925,6 +928,8 @@ bool Engine::pipe_ready() {
     for (int i = 0; i < kPipeRing && ok; ++i)
         for (int l = 0; l < kGruLayers && ok; ++l)
             if (!pipe_ev_[i][l]) ok = hipEventCreateWithFlags(&pipe_ev_[i][l], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < kPipeRing && ok; ++i)
+        if (!pipe_syn_[i]) ok = hipEventCreateWithFlags(&pipe_syn_[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         (void) hipGetLastError();
         pipe_failed_ = true;  // (the plain chunked route stays)
@@ -1069,10 +1074,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     feat_valid_ = !roll_in_analysis;  // (otherwise the features went to the history slots)
     const int16_t *hist_before = d_hist_[hist_cur_];
     const int only = dev_only_class_;  // -1 in the product library
-    tick(kClsAnalysis);
-    if (only < 0 || only == kClsAnalysis) launch_analysis(an, stream_);
-    tock(kClsAnalysis);
-    if (!in_place) hist_cur_ ^= 1;
+    // (the analysis launch itself follows the route decisions below: the layer pipeline of mid-size batches cuts it into slices of frames)
 
     // Time slice of the call the launches below work on, and where they go: the whole call on the handle's stream -- or, for mid-size
     // batches, one of its sub-chunks on one of the pipeline streams (run_pipelined below).  Every activation matrix is frame-major
@@ -1201,6 +1203,44 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
 
     const bool small_steps = T > 1 && mtb <= steps_mt && prec_ != kBf16 && !no_small_ && !wave;
     last_route_ = small ? kRouteSmall : wave ? kRouteWave : small_steps ? kRouteSmallSteps : quad ? kRouteQuad1 : kRouteChunked;
+    // ---- mid-size batches: the layer pipeline over sub-chunks of frames (see the chunk loop below)
+    const int pipe_chunk = dev_pipe_chunk_ > 0 ? dev_pipe_chunk_ : (T + 1) / 2;
+    const int pipe_mt = dev_pipe_mt_ >= 0 ? dev_pipe_mt_ : 144;
+    const int pipe_grid = dev_pipe_grid_ > 0 ? dev_pipe_grid_ : 128;
+    const int pipe_streams = dev_pipe_streams_ > 0 && dev_pipe_streams_ <= kPipeStreams ? dev_pipe_streams_ : 2;
+    const bool pipelined = !wave && !small && !small_steps && !quad && prec_ == kBf16 && mtb <= pipe_mt && T >= 32 && T >= 2 * pipe_chunk - 1 && !profiling_ &&
+                           !debug_taps_ && only < 0 && pipe_ready();
+    int nchunks = 1;
+    if (pipelined) {
+        nchunks = (T + pipe_chunk - 1) / pipe_chunk;
+        if (T - (nchunks - 1) * pipe_chunk < pipe_chunk / 2 && nchunks > 2) --nchunks;  // (a short tail joins the last chunk)
+    }
+    // ... whose analysis and synthesis are cut into the same slices of frames when the spectrum is rebuilt from the PCM and the front-end
+    // is folded (no launch between analysis and the first stage): slice c's analysis then runs beside slice c - 1's layers and slice
+    // c's synthesis beside slice c + 1's -- 96 of a 1 024-stream call's 1 157 us were the two STFT launches alone at either end
+    // (measured, tools/pipe_sweep.py: +1.3 % at 1 024 and 1 536 streams x 64 frames, nothing at 800, -0.3 % at 2 048; at 32 frames per call
+    // -1 ... -1.5 % from 1 024 streams on -- the slices' launches then cost what their overlap gives: long calls of up to 112 m-tiles only)
+    const bool stft_sliced = pipelined && fold_ && recompute && !an.write_spec && taps_ == 1 && !dev_pipe_whole_stft_ &&
+                             (dev_pipe_chunk_ > 0 || (T >= 48 && mtb <= 112));
+    auto analysis_slice = [&](int t0c, int Tc, bool first, bool last, hipStream_t st) {
+        AnalysisArgs a = an;
+        a.pcm = d_pcm + (size_t) t0c * kFrame;
+        a.feat = feat_now + (size_t) t0c * feat_frame_bytes_;
+        a.T = Tc;
+        a.pitch = T;
+        a.prev_in_pcm = first ? 0 : 1;
+        a.write_hist = last ? 1 : 0;
+        int seg = Tc;
+        while (seg > 1 && (Bpad_ / 16) * ((Tc + seg - 1) / seg) < 1024) seg = (seg + 1) / 2;
+        a.seg = dev_analysis_seg_ > 0 ? (dev_analysis_seg_ < Tc ? dev_analysis_seg_ : Tc) : seg;
+        launch_analysis(a, st);
+    };
+    if (!stft_sliced) {
+        tick(kClsAnalysis);
+        if (only < 0 || only == kClsAnalysis) launch_analysis(an, stream_);
+        tock(kClsAnalysis);
+    }
+    if (!in_place) hist_cur_ ^= 1;
     // front-end: e = features . W_in + b_in
     // (bf16 with a one-frame front-end: folded into the stage-input GEMMs, which read the features themselves -- no launch, no `e`)
     if (!fold_)
@@ -1234,18 +1274,43 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     // Measured (tools/pipe_sweep.py, profiles/r06_pipe_sweep.txt): TWO sub-chunks on two streams is the best form at every size -- 64 frames x
     // 1 024 streams 1.34 -> 1.06 ms, x 2 048 streams 1.68 -> 1.48 ms; three chunks equal it, four and more lose (a launch of 8-16 frames is
     // mostly prologue, and every cross-stream event costs microseconds) -- and it stops paying at 160 m-tiles.
-    const int pipe_chunk = dev_pipe_chunk_ > 0 ? dev_pipe_chunk_ : (T + 1) / 2;
-    const int pipe_mt = dev_pipe_mt_ >= 0 ? dev_pipe_mt_ : 144;
-    const int pipe_grid = dev_pipe_grid_ > 0 ? dev_pipe_grid_ : 128;
-    const int pipe_streams = dev_pipe_streams_ > 0 && dev_pipe_streams_ <= kPipeStreams ? dev_pipe_streams_ : 2;
-    const bool pipelined = !wave && !small && !small_steps && !quad && prec_ == kBf16 && mtb <= pipe_mt && T >= 32 && T >= 2 * pipe_chunk - 1 && !profiling_ &&
-                           !debug_taps_ && only < 0 && pipe_ready();
-    int nchunks = 1;
-    if (pipelined) {
-        nchunks = (T + pipe_chunk - 1) / pipe_chunk;
-        if (T - (nchunks - 1) * pipe_chunk < pipe_chunk / 2 && nchunks > 2) --nchunks;  // (a short tail joins the last chunk)
-        (void) hipEventRecord(pipe_fork_, stream_);
-    }
+    // synthesis of frames [t0c, t0c + Tc) of the call (the whole call unless the STFT stages are sliced): slice number `ci` reads the
+    // overlap-add tail from ping-pong buffer (tail_cur_ + ci) & 1 and leaves it in the other one
+    auto synthesis_slice = [&](int t0c, int Tc, int ci, hipStream_t st) {
+        SynthesisArgs sy;
+        sy.spec = d_spec_;
+        sy.mask = (const float *) ((const char *) d_mask_ + (size_t) t0c * mtb * kMaskTiles * 256 * (prec_ == kBf16 ? 2 : 4));
+        sy.window = d_window_;
+        sy.twiddle = d_twiddle_;
+        const int tc = (tail_cur_ + ci) & 1;
+        sy.tail_in = d_tail_[tc];
+        sy.tail_out = d_tail_[in_place ? tc : tc ^ 1];
+        const int seg_env = dev_synth_seg_;
+        // two segments per stream tile (512 workgroups at B = 4096) measured best: fewer, longer segments amortise the
+        // one replayed frame; a single segment leaves half the chip without a second workgroup to overlap with
+        // ... and with few stream tiles the segments shrink (down to one frame) until there are about two workgroups per CU
+        int seg_auto = Tc <= 4 ? Tc : ((Tc + 1) / 2 > 4 ? (Tc + 1) / 2 : 4);
+        while (seg_auto > 1 && mtb * ((Tc + seg_auto - 1) / seg_auto) < 512) seg_auto = (seg_auto + 1) / 2;  // (few streams: down to one frame + its replay)
+        const int seg = seg_env > 0 ? seg_env : seg_auto;
+        sy.seg = Tc <= seg ? Tc : seg;
+        sy.out = d_out + (size_t) t0c * kFrame;
+        sy.pcm = d_pcm + (size_t) t0c * kFrame;
+        sy.hist_in = hist_before;
+        sy.recompute = recompute;
+        sy.mask_fp16 = prec_ == kBf16;
+        if (mask_in_synthesis) {
+            sy.mask_h = d_hseq_b_;
+            sy.mask_w = sd_[kStages - 1].w_head;
+            sy.mask_b = sd_[kStages - 1].b_head;
+        }
+        sy.B = B_;
+        sy.Bpad = Bpad_;
+        sy.T = Tc;
+        sy.pitch = T;
+        sy.prev_in_pcm = t0c > 0 ? 1 : 0;
+        launch_synthesis(sy, st);
+    };
+    if (pipelined) (void) hipEventRecord(pipe_fork_, stream_);
     for (int c = 0; c < nchunks && !wave; ++c) {
       if (pipelined) {
           c_t0 = c * pipe_chunk;
@@ -1254,6 +1319,7 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
           c_stream = pipe_stream_[c % pipe_streams];
           c_grid = pipe_grid;
           if (c < pipe_streams) (void) hipStreamWaitEvent(c_stream, pipe_fork_, 0);
+          if (stft_sliced) analysis_slice(c_t0, c_T, c == 0, c == nchunks - 1, c_stream);
       }
       auto gru_dep = [&](const void *whh, const float *bhh, int layer, void *hseq, const StageDev *head = nullptr) {
           if (pipelined && c > 0) (void) hipStreamWaitEvent(c_stream, pipe_ev_[(c - 1) % kPipeRing][layer], 0);
@@ -1305,6 +1371,11 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
         else if (!mask_in_synthesis)
             gemm(kClsGemmHead, nullptr, 0, d_hseq_b_, nbh_, d.w_head, d.b_head, d_mask_, d.head_tiles, kBins, kOutMask);
     }
+      if (stft_sliced) {  // this slice's synthesis, behind the previous slice's (the overlap-add tail goes from one to the next)
+          if (c > 0) (void) hipStreamWaitEvent(c_stream, pipe_syn_[(c - 1) % kPipeRing], 0);
+          synthesis_slice(c_t0, c_T, c, c_stream);
+          if (c + 1 < nchunks) (void) hipEventRecord(pipe_syn_[c % kPipeRing], c_stream);
+      }
       if (pipelined && (c >= nchunks - pipe_streams)) {  // the last chunk of each stream: the handle's stream continues behind it
           (void) hipEventRecord(pipe_join_[c % pipe_streams], c_stream);
           (void) hipStreamWaitEvent(stream_, pipe_join_[c % pipe_streams], 0);
@@ -1312,40 +1383,14 @@ bool Engine::run_device(int T, const int16_t *d_pcm, int16_t *d_out, std::string
     }
     c_t0 = 0, c_T = T, c_hs = hs_cur_, c_stream = stream_, c_grid = 0;
 
-    SynthesisArgs sy;
-    sy.spec = d_spec_;
-    sy.mask = d_mask_;
-    sy.window = d_window_;
-    sy.twiddle = d_twiddle_;
-    sy.tail_in = d_tail_[tail_cur_];
-    sy.tail_out = d_tail_[in_place ? tail_cur_ : tail_cur_ ^ 1];
-    const int seg_env = dev_synth_seg_;
-    // two segments per stream tile (512 workgroups at B = 4096) measured best: fewer, longer segments amortise the
-    // one replayed frame; a single segment leaves half the chip without a second workgroup to overlap with
-    // ... and with few stream tiles the segments shrink (down to one frame) until there are about two workgroups per CU
-    int seg_auto = T <= 4 ? T : ((T + 1) / 2 > 4 ? (T + 1) / 2 : 4);
-    while (seg_auto > 1 && mtb * ((T + seg_auto - 1) / seg_auto) < 512) seg_auto = (seg_auto + 1) / 2;  // (few streams: down to one frame + its replay)
-    const int seg = seg_env > 0 ? seg_env : seg_auto;
-    sy.seg = T <= seg ? T : seg;
-    sy.out = d_out;
-    sy.pcm = d_pcm;
-    sy.hist_in = hist_before;
-    sy.recompute = recompute;
-    sy.mask_fp16 = prec_ == kBf16;
-    if (mask_in_synthesis) {
-        sy.mask_h = d_hseq_b_;
-        sy.mask_w = sd_[kStages - 1].w_head;
-        sy.mask_b = sd_[kStages - 1].b_head;
+    if (!stft_sliced) {
+        tick(kClsSynthesis);
+        if (only < 0 || only == kClsSynthesis) synthesis_slice(0, T, 0, stream_);
+        tock(kClsSynthesis);
     }
-    sy.B = B_;
-    sy.Bpad = Bpad_;
-    sy.T = T;
-    tick(kClsSynthesis);
-    if (only < 0 || only == kClsSynthesis) launch_synthesis(sy, stream_);
-    tock(kClsSynthesis);
     hs_cur_ = small_steps || wave ? (hs_cur_ + T) & 1 : pipelined ? (hs_cur_ + nchunks) & 1 : hs_cur_ ^ 1;
     if (pipelined) last_route_ = kRoutePipelined;
-    if (!in_place) tail_cur_ ^= 1;
+    if (!in_place) tail_cur_ = stft_sliced ? (tail_cur_ + nchunks) & 1 : tail_cur_ ^ 1;
 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

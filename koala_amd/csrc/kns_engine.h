@@ -136,8 +136,8 @@ private:
     // mid-size batches: the (layer, chunk-of-frames) grid of a call as a wavefront over a few streams (kns_engine.cpp, run_device)
     static constexpr int kPipeStreams = 4, kPipeRing = 2;
     hipStream_t pipe_stream_[kPipeStreams] = {};
-    hipEvent_t pipe_fork_ = nullptr, pipe_join_[kPipeStreams] = {}, pipe_ev_[kPipeRing][kGruLayers] = {};
-    bool pipe_ok_ = false, pipe_failed_ = false;
+    hipEvent_t pipe_fork_ = nullptr, pipe_join_[kPipeStreams] = {}, pipe_ev_[kPipeRing][kGruLayers] = {}, pipe_syn_[kPipeRing] = {};
+    bool pipe_ok_ = false, pipe_failed_ = false, dev_pipe_whole_stft_ = false;
     bool pipe_ready();
     void run_wave(int T, int mtb);
     // asynchronous host calls: two slots of full-size device staging (slot 0 = d_in_ / d_out_, slot 1 allocated on first use)

@@ -53,6 +53,10 @@ struct AnalysisArgs {
     // -> 0 .. hist_slots - 1), so that afterwards the slots are the front-end's taps, oldest first -- no copy launches
     void *feat_hist = nullptr;
     int hist_slots = 0;
+    // a SLICE of frames of a longer call (the layer pipeline of mid-size batches, kns_engine.cpp): `pcm` points at the slice's first frame,
+    // rows are `pitch` frames apart (0: T), the frame in front of the slice is read from the row itself instead of `hist_in`, and only the
+    // call's last slice leaves the history behind
+    int pitch = 0, prev_in_pcm = 0, write_hist = 1;
 };
 void launch_analysis(const AnalysisArgs &a, hipStream_t s);
 
@@ -73,6 +77,9 @@ struct SynthesisArgs {
     int mask_fp16 = 0;
     // optional (one-frame calls, bf16, stored spectrum): the mask head sigmoid(h . W_mask + b_mask) inside this launch -- four
     // further waves compute the workgroup's mask tile into LDS while the STFT waves fetch their operands; `mask` is not read then
+    // a slice of frames of a longer call: `pcm` / `out` point at the slice's first frame, rows `pitch` frames apart (0: T); recompute: the
+    // frame in front of the slice comes from the `pcm` row itself instead of `hist_in`
+    int pitch = 0, prev_in_pcm = 0;
     const void *mask_h = nullptr;    // A-packed hidden sequence of the last stage's layer B [mtiles][9]
     const void *mask_w = nullptr;    // B-packed [17][9]
     const float *mask_b = nullptr;   // [17 * 16]

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 3) void analysis_kernel(AnalysisArgs g) {
     const int mt = blockIdx.x, mtiles = g.Bpad >> 4;
     const int t0 = blockIdx.y * g.seg, t1 = min(g.T, t0 + g.seg);
     const int b = mt * 16 + row;
-    const size_t row_len = (size_t) g.T * kFrame;
+    const size_t row_len = (size_t) (g.pitch ? g.pitch : g.T) * kFrame;
     // rows past the last stream (ragged last tile) read the last stream's samples: their results are never stored
     // anywhere a stream would see them, and the loop carries no conditional vector-memory operation
     const int16_t *pcm_row = g.pcm + (size_t) (b < g.B ? b : g.B - 1) * row_len;
@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256, 3) void analysis_kernel(AnalysisArgs g) {
         }
     }
     int prev[8], cur[8], nxt[8];
-    load_frame(prev, t0 == 0 ? g.hist_in + (size_t) b * kFrame : pcm_row + (size_t) (t0 - 1) * kFrame, c);
+    // (a slice of a longer call, prev_in_pcm: the frame in front of frame 0 sits in the row itself, at t = -1)
+    load_frame(prev, t0 == 0 && !g.prev_in_pcm ? g.hist_in + (size_t) b * kFrame : pcm_row + ((ptrdiff_t) t0 - 1) * kFrame, c);
     load_frame(cur, pcm_row + (size_t) t0 * kFrame, c);
     StftTables tbl;
     stft_request_tables(tbl, g.twiddle, g.window, tid);
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256, 3) void analysis_kernel(AnalysisArgs g) {
             cur[jj] = nxt[jj];
         }
     }
-    if (t1 == g.T && b < g.B) {  // history for the next call: the last frame (prev after the final rotation)
+    if (t1 == g.T && b < g.B && g.write_hist) {  // history for the next call: the last frame (prev after the final rotation)
         int *h = (int *) (g.hist_out + (size_t) b * kFrame);
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) h[16 * jj + c] = prev[jj];
@@ -297,12 +298,12 @@ __global__ __launch_bounds__(kMaskIn ? 512 : 256, kMaskIn ? 1 : 3) void synthesi
     const int tb = t0 > 0 ? t0 - 1 : 0;
     const int b = mt * 16 + row;
     const bool valid = b < g.B;
-    const size_t row_len = (size_t) g.T * kFrame;
+    const size_t row_len = (size_t) (g.pitch ? g.pitch : g.T) * kFrame;
     const int16_t *pcm_row = g.pcm + (size_t) (valid ? b : g.B - 1) * row_len;  // (ragged tile: see analysis_kernel)
 
     int prev[8], cur[8], nxt[8];
     if (kRecompute) {
-        load_frame(prev, tb == 0 ? g.hist_in + (size_t) b * kFrame : pcm_row + (size_t) (tb - 1) * kFrame, c);
+        load_frame(prev, tb == 0 && !g.prev_in_pcm ? g.hist_in + (size_t) b * kFrame : pcm_row + ((ptrdiff_t) tb - 1) * kFrame, c);
         load_frame(cur, pcm_row + (size_t) tb * kFrame, c);
     }
     // overlap-add tail of this lane's points n = c + 16 k2, k2 = 8..15 (samples 2n, 2n + 1 of the block's second half)

@@ -421,11 +421,12 @@ def test_alternative_kernels_give_identical_pcm(random_model, random5_model):
                    'KOALA_AMD_GEMM_NO_WSR', 'KOALA_AMD_NO_SMALL', 'KOALA_AMD_NO_GRAPH', 'KOALA_AMD_STORE_SPECTRUM',
                    'KOALA_AMD_DEBUG_TAPS', 'KOALA_AMD_NO_QUAD', 'KOALA_AMD_NO_HEAD_FUSE', 'KOALA_AMD_NO_STFT_FUSE', 'KOALA_AMD_WAVE_MT=0',
                    'KOALA_AMD_WAVE_MT=4096', 'KOALA_AMD_WAVE_GROUP=2', 'KOALA_AMD_NO_SPIN_WAIT', 'KOALA_AMD_PIPE_MT=0', 'KOALA_AMD_PIPE_CHUNK=8',
-                   'KOALA_AMD_NO_WEIGHT_CACHE'):  # (KOALA_AMD_NO_QUAD: one-frame calls of large
+                   'KOALA_AMD_PIPE_WHOLE_STFT', 'KOALA_AMD_NO_WEIGHT_CACHE'):  # (KOALA_AMD_NO_QUAD: one-frame calls of large
         # batches through input GEMM + recurrent kernel instead of the one-step quad kernel, kns_gruq.hip; KOALA_AMD_WAVE_MT: multi-frame
         # calls never / always as a wavefront over (layer, frame), kns_gru.hip gru_wave_kernel; _GROUP: its m-tiles per workgroup;
         # KOALA_AMD_NO_SPIN_WAIT: one-frame host calls wait in hipStreamSynchronize instead of spinning on the frame's completion word;
-        # KOALA_AMD_PIPE_MT=0: mid-size batches never as a layer pipeline over sub-chunks of frames, _CHUNK: its frames per sub-chunk)
+        # KOALA_AMD_PIPE_MT=0: mid-size batches never as a layer pipeline over sub-chunks of frames, _CHUNK: its frames per sub-chunk,
+        # _WHOLE_STFT: its analysis and synthesis as whole-call launches instead of per sub-chunk)
         env = dict(os.environ)
         if switch:
             env[switch.split('=')[0]] = switch.split('=')[1] if '=' in switch else '1'

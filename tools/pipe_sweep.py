@@ -18,7 +18,7 @@ st = torch.cuda.Stream()
 torch.cuda.set_stream(st)
 arms = [('one launch per layer (rounds 1-5)', {'KOALA_AMD_PIPE_MT': '0'}), ('pipelined, 16 frames per sub-chunk', {'KOALA_AMD_PIPE_MT': '4096'}),
         ('pipelined, 8', {'KOALA_AMD_PIPE_MT': '4096', 'KOALA_AMD_PIPE_CHUNK': '8'}), ('pipelined, 32', {'KOALA_AMD_PIPE_MT': '4096', 'KOALA_AMD_PIPE_CHUNK': '32'}),
-        ('product default', {})]
+        ('pipelined, whole-call STFT launches', {'KOALA_AMD_PIPE_MT': '144', 'KOALA_AMD_PIPE_WHOLE_STFT': '1'}), ('product default', {})]
 if os.environ.get('SWEEP_GRID'):  # chunk x grid arms
     arms = [('one launch per layer', {'KOALA_AMD_PIPE_MT': '0'})] + [
         ('chunk %s grid %s streams %s' % (c, g, n), {'KOALA_AMD_PIPE_MT': '4096', 'KOALA_AMD_PIPE_CHUNK': c, 'KOALA_AMD_PIPE_GRID': g, 'KOALA_AMD_PIPE_STREAMS': n})
@@ -30,7 +30,7 @@ for T in [int(v) for v in os.environ.get('SWEEP_T', '64,32').split(',')]:
         y = torch.zeros_like(x)
         row = []
         for name, env in arms:
-            for k in ('KOALA_AMD_PIPE_MT', 'KOALA_AMD_PIPE_CHUNK', 'KOALA_AMD_PIPE_GRID', 'KOALA_AMD_PIPE_STREAMS'):
+            for k in ('KOALA_AMD_PIPE_MT', 'KOALA_AMD_PIPE_CHUNK', 'KOALA_AMD_PIPE_GRID', 'KOALA_AMD_PIPE_STREAMS', 'KOALA_AMD_PIPE_WHOLE_STFT'):
                 os.environ.pop(k, None)
             os.environ.update(env)
             kb = koala_amd.create_batch('key', B, T, 'bf16', model_path=model, library_path=koala_amd.developer_library_path())
