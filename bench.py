@@ -435,6 +435,21 @@ def extra_points(args, torch, np, koala_amd, model, kb, x, dx, dy, base, local_r
         except Exception as e:  # noqa: BLE001
             out['fp32_b4096_T64'] = {'error': repr(e)[:300]}
 
+    # -- mid-size batches: the layers of a call as a wavefront over two sub-chunks of frames (round 6; kns_engine.cpp, kRoutePipelined)
+    for Bm in (1024, 2048):
+        try:
+            km = koala_amd.create_batch('bench', Bm, T, args.precision, model_path=model, device=dev, library_path=args.library)
+            km.set_stream(torch.cuda.current_stream().cuda_stream)
+            xm = dx[:Bm].contiguous()
+            ym = torch.empty_like(xm)
+            dt = time_steps(lambda: km.process_device(T, xm.data_ptr(), ym.data_ptr()), sync, 60, 10)
+            km.set_stream(0)
+            km.delete()
+            out['mid_b%d_T%d' % (Bm, T)] = {'workload': '%d streams x %d frames per call, %s, device-resident' % (Bm, T, args.precision),
+                                            'frames_per_s': round(Bm * T * 60 / dt, 1), 'ms_per_call': round(dt / 60 * 1e3, 4)}
+        except Exception as e:  # noqa: BLE001
+            out['mid_b%d_T%d' % (Bm, T)] = {'error': repr(e)[:200]}
+
     # -- the many-files mode's shape (koala_amd/demo/koala_demo_file.py: a few files x 32 frames per call): 16 streams, both precisions
     for prec in ('bf16', 'fp32'):
         k1 = koala_amd.create_batch('bench', 16, 32, prec, model_path=model, device=dev, library_path=args.library)
