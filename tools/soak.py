@@ -22,7 +22,10 @@ def main():
     rng = np.random.default_rng(7)
     cases = [('random', 'bf16', 4096, 8, 60), ('random', 'fp32', 1000, 8, 40), ('random', 'bf16', 300, 16, 80), ('random5', 'bf16', 1030, 6, 60),
              ('random5', 'fp32', 77, 9, 60), ('adaptive', 'bf16', 2048, 4, 40), ('adaptive', 'fp32', 256, 32, 12), ('random', 'bf16', 17, 5, 200),
-             ('random', 'fp32', 16, 3, 200), ('random', 'fp32', 200, 12, 60), ('random5', 'bf16', 100, 9, 60), ('random', 'bf16', 500, 40, 30)]
+             ('random', 'fp32', 16, 3, 200), ('random', 'fp32', 200, 12, 60), ('random5', 'bf16', 100, 9, 60), ('random', 'bf16', 500, 40, 30),
+             # mid-size batches: calls of 32 frames and more take the layer pipeline over sub-chunks (long ones with sliced STFT stages), shorter
+             # ones the plain route -- state handed back and forth between the two, with resets
+             ('random', 'bf16', 1200, 64, 24), ('adaptive', 'bf16', 1024, 56, 16), ('random5', 'bf16', 2000, 40, 12)]
     only = os.environ.get('SOAK_ONLY')  # e.g. adaptive:bf16
     if only:
         cases = [c for c in cases if '%s:%s' % (c[0], c[1]) == only]
