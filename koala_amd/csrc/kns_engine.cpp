@@ -997,6 +997,10 @@ void Engine::run_wave(int T, int mtb) {
 //   | bf16          | > 1      | <= 48 (<= 64 up to T = 4)             | kRouteWave: gru_wave_kernel, T + 10 launches: the (stage,     |
 //   |               |          |                                       |   frame) items of one anti-diagonal side by side, one layer   |
 //   |               |          |                                       |   per XCD, narrow heads as items of their own                 |
+//   | bf16          | >= 32    | 49 .. 144                             | kRoutePipelined: the chunked kernels on TWO sub-chunks of     |
+//   |               |          |                                       |   frames, the (layer, sub-chunk) grid as a wavefront over two |
+//   |               |          |                                       |   streams; >= 48 frames and <= 112 m-tiles: analysis and      |
+//   |               |          |                                       |   synthesis per sub-chunk too                                 |
 //   | bf16          | > 1      | otherwise                             | kRouteChunked: gemm_ws2 (m-tiles in multiples of 256 x stage; |
 //   |               |          |                                       |   the rest through gemm_kernel) + gru_resident8_kernel        |
 //   | fp32          | 1        | <= 256                                | kRouteSmall                                                   |

@@ -637,12 +637,13 @@ def test_dispatch_boundaries(random_model, precision, B, T):
 @pytest.mark.parametrize('precision,B,T,route', [('bf16', 16, 1, 1), ('bf16', 944, 1, 1), ('bf16', 960, 1, 3), ('bf16', 976, 1, 1),
                                                  ('bf16', 3072, 1, 3), ('bf16', 3088, 1, 0), ('bf16', 4096, 1, 3), ('bf16', 64, 4, 4),
                                                  ('bf16', 768, 8, 4), ('bf16', 784, 8, 0), ('bf16', 1024, 4, 4), ('bf16', 1024, 5, 0), ('bf16', 1040, 2, 0),
-                                                 ('bf16', 4096, 4, 0), ('fp32', 256, 1, 1), ('fp32', 4096, 1, 1), ('fp32', 4112, 1, 0),
+                                                 ('bf16', 4096, 4, 0), ('bf16', 1024, 64, 5), ('bf16', 1024, 31, 0), ('bf16', 2304, 32, 5), ('bf16', 2320, 32, 0), ('bf16', 784, 32, 5),
+                                                 ('fp32', 256, 1, 1), ('fp32', 4096, 1, 1), ('fp32', 4112, 1, 0),
                                                  ('fp32', 64, 2, 4), ('fp32', 256, 32, 4), ('fp32', 4096, 2, 4), ('fp32', 4112, 2, 0)])
 def test_dispatch_routes(random_model, precision, B, T, route):
     """The dispatch table at the head of Engine::run_device (kns_engine.cpp), row by row: the developer build says which kernel
     family the last call took (0 chunked, 1 low-latency layer kernel, 2 the same frame by frame, 3 one-step quad kernel, 4 wavefront over
-    (layer, frame)) and what
+    (layer, frame), 5 chunked kernels as a layer pipeline over two sub-chunks of frames) and what
     rode inside other launches."""
     torch = pytest.importorskip('torch')
     kb = koala_amd.create_batch('key', B, T, precision, model_path=random_model, library_path=DEV_LIB)
